@@ -1,0 +1,96 @@
+"""ctypes loader for libsmt_hip.so -- the C ABI declared in include/smt_hip.h."""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsmt_hip.so")
+ABI_VERSION = 1
+
+_lib = None
+_lock = threading.Lock()
+
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_f32 = ctypes.c_float
+c_ptr = ctypes.c_void_p
+c_size = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/smt_hip.h one to one
+_SIGNATURES = {
+    "smt_last_error": (ctypes.c_char_p, []),
+    "smt_abi_version": (c_int, []),
+    "smt_vq_forward_workspace_bytes": (c_size, [c_i64, c_int, c_int]),
+    "smt_vq_forward": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size,
+                               c_ptr]),
+    "smt_vq_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
+    "smt_vq_ema_accumulate": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr]),
+    "smt_vq_ema_apply": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_int, c_int, c_ptr, c_ptr]),
+}
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """Load (once) and return the ctypes handle; fail loudly if it is missing."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise NativeLibraryError(
+                        f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(there is no CPU/eager fallback for the hot path)")
+                handle = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in _SIGNATURES.items():
+                    fn = getattr(handle, name)  # AttributeError if the .so is stale
+                    fn.restype = res
+                    fn.argtypes = args
+                if handle.smt_abi_version() != ABI_VERSION:
+                    raise NativeLibraryError("libsmt_hip.so ABI version mismatch; rebuild")
+                _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().smt_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (status {status}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (or NULL for None) as a void*."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "native ops need contiguous device tensors"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Workspace:
+    """Grow-only per-device scratch buffer handed to the kernels (the library never allocates)."""
+
+    def __init__(self):
+        self._buf = {}
+
+    def get(self, nbytes, device):
+        key = (device.type, device.index)
+        buf = self._buf.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            self._buf[key] = buf
+        return buf
+
+
+workspace = Workspace()

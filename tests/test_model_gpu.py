@@ -1,0 +1,130 @@
+"""End-to-end VQ-VAE (product path on the GPU) against goldens captured from the reference
+and against the oracle.  fp32 compute; tolerances stated per assert."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vqvae_oracle as orc
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def small_config(dropout=0.0, **model_over):
+    from utils import config as C
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "speech-masters-thesis_amd")
+    cfg = C.merge(C.load(os.path.join(root, "configs/models/vqvae.yaml")),
+                  C.load(os.path.join(root, "configs/datasets/synthetic_ljspeech.yaml")),
+                  C.create({"train": {"batch_size": 3, "n_gpus": 1}}))
+    cfg.model.update(C.create(dict(width=16, emb_width=32, l_bins=64, multipliers=[1, 1, 1], dropout=dropout)))
+    cfg.model.loss.linf_topk = 128
+    cfg.model.update(C.create(model_over))
+    return cfg
+
+
+def build(golden_params, cfg):
+    from models.vqvae.vqvae import VQVAE
+    model = VQVAE(cfg).cuda()
+    sd = {k: T(v) for k, v in golden_params.items()}
+    sd["bottleneck.level_blocks.0.k"] = torch.zeros(cfg.model.l_bins, cfg.model.emb_width)
+    model.load_state_dict(sd)
+    return model
+
+
+def params_from(g, prefix):
+    return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix)}
+
+
+def test_eval_step_matches_reference(golden):
+    g = golden("vqvae_small")
+    # the fixture's codebook has 36 rows (every valid latent row of the batch)
+    model = build(params_from(g, "p."), small_config(l_bins=int(g["k0"].shape[0])))
+    blk = model.bottleneck.level_blocks[0]
+    blk.k.copy_(T(g["k0"]))
+    blk.init = True
+    model.eval()
+    x, lens = T(g["x"]).cuda(), T(g["lens"]).cuda()
+    codes, z_lens = model.encode_and_quantize(x, lens)
+    assert np.array_equal(codes.cpu().numpy(), g["enc_codes"])          # bit-exact code indices
+    loss_dict, metrics = model.supervised_step([None, None, None, None, x, lens, None])
+    assert metrics == {}
+    loss_dict["loss"].backward()
+    for kk in ("loss", "loss_recon", "loss_stft", "loss_commit"):
+        # fp32 end-to-end through ~60 conv layers on a different summation order: 1e-4 relative
+        assert np.isclose(loss_dict[kk].item(), float(g["eval_" + kk]), rtol=1e-4), kk
+    assert torch.allclose(loss_dict["yh"].cpu(), T(g["eval_yh"]), atol=5e-5)
+    assert torch.equal(loss_dict["y"].cpu(), T(g["x"])[:, 0])
+    named = dict(model.named_parameters())
+    checked = 0
+    for key, v in g.items():
+        if key.startswith("eval_g."):
+            ref = T(v)
+            got = named[key[len("eval_g."):]].grad
+            assert got is not None, key
+            assert (got.cpu() - ref).abs().max() <= 1e-2 * ref.abs().max() + 1e-7, key  # fp32 cancellation noise
+            checked += 1
+    assert checked > 100
+
+
+def test_train_steps_match_reference(golden):
+    """Two train-mode steps (dropout 0, captured k_rand) with AdamW; step 1 restarts from the
+    reference's post-step-0 parameters (see tests/golden/make_golden.py)."""
+    g = golden("vqvae_train")
+    cfg = small_config(dropout=0.0)
+    model = build(params_from(g, "p."), cfg)
+    model.train()
+    lens = T(g["lens"]).cuda()
+    blk = model.bottleneck.level_blocks[0]
+    for step in range(2):
+        if step == 1:
+            with torch.no_grad():
+                for n, p in model.named_parameters():
+                    p.copy_(T(g["p1." + n]))
+        model.zero_grad()
+        x = T(g[f"tr{step}_x"]).cuda()
+        kw = dict(k_rand=T(g[f"tr{step}_k_rand"]).cuda())
+        if step == 0:
+            kw["k_rand_init"] = T(g["tr0_k_rand_init"]).cuda()
+        loss_dict, metrics = model(x, lens, **kw)
+        loss_dict["loss"].backward()
+        for kk in ("loss", "loss_recon", "loss_stft", "loss_commit"):
+            assert np.isclose(loss_dict[kk].item(), float(g[f"tr{step}_{kk}"]), rtol=2e-4), (step, kk)
+        assert torch.allclose(loss_dict["yh"].cpu(), T(g[f"tr{step}_yh"]), atol=1e-4)
+        for mk in ("fit", "entropy", "used_curr", "usage", "dk"):
+            assert np.isclose(float(metrics[mk]), float(g[f"tr{step}_m_{mk}"]), rtol=2e-4), (step, mk)
+        for name, tns in (("k", blk.k), ("k_sum", blk.k_sum), ("k_elem", blk.k_elem)):
+            assert torch.allclose(tns.cpu(), T(g[f"tr{step}_{name}"]), atol=2e-5), name
+        named = dict(model.named_parameters())
+        for key, v in g.items():
+            if key.startswith(f"tr{step}_g."):
+                ref = T(v)
+                got = named[key.split("_g.", 1)[1]].grad.cpu()
+                assert (got - ref).abs().max() <= 1e-2 * ref.abs().max(), key
+        gnorm = torch.sqrt(sum((p.grad ** 2).sum() for p in model.parameters()))
+        assert np.isclose(gnorm.item(), float(g[f"tr{step}_gnorm"]), rtol=2e-3)
+
+
+def test_full_size_train_step_runs_and_is_finite():
+    from utils import config as C
+    from utils.commons import get_model, get_optimizer
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "speech-masters-thesis_amd")
+    cfg = C.merge(C.load(os.path.join(root, "configs/models/vqvae_k256.yaml")),
+                  C.load(os.path.join(root, "configs/datasets/synthetic_ljspeech.yaml")),
+                  C.create({"train": {"batch_size": 2, "n_gpus": 1, "ema": True}}))
+    model, ema = get_model(cfg, "cuda")
+    opt, sched = get_optimizer(cfg, model)
+    x = orc.synthetic_clip_batch(2, 16384, 3).cuda()
+    lens = torch.tensor([16384, 12288]).cuda()
+    model.train()
+    prev = None
+    for _ in range(3):
+        opt.zero_grad()
+        loss_dict, metrics = model.supervised_step([None, None, None, None, x, lens, None])
+        loss_dict["loss"].backward()
+        opt.step(); sched.step(); ema.step()
+        assert torch.isfinite(loss_dict["loss"])
+        assert set(metrics) == {"fit", "entropy", "used_curr", "usage", "dk"}
+        prev = loss_dict["loss"].item()
+    assert cfg.dataset.use_spect is False and cfg.dataset.use_token is False   # get_model's flag surgery

@@ -1,0 +1,137 @@
+"""VQ kernels (libsmt_hip.so through the C ABI) against the oracle and the
+reference goldens.  Index comparisons are BIT-EXACT; float outputs carry the
+fp32 tolerance written at each assert."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vqvae_oracle as orc
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def dev(a):
+    return (T(a) if isinstance(a, np.ndarray) else a).cuda().contiguous()
+
+
+def run_fwd(x, k, mask=None):
+    from smt_amd import vq
+    idx, md, xd, sums = vq.vq_forward_raw(dev(x), dev(k), None if mask is None else dev(mask))
+    torch.cuda.synchronize()
+    return idx.cpu().numpy(), md.cpu().numpy(), xd.cpu().numpy(), sums.cpu().numpy()
+
+
+def test_golden_indices_bit_exact(golden):
+    g = golden("vq_quantize")
+    for tag in ("gauss", "enc"):
+        x, k, mask = g[f"{tag}_x"], g[f"{tag}_k"], g[f"{tag}_mask"][:, 0].copy()
+        idx, md, xd, sums = run_fwd(x, k, mask)
+        exact, d1, _ = orc.vq_argmin_exact(x, k)
+        assert np.array_equal(idx, exact)                       # bit-exact vs the oracle, every row
+        pinned = g[f"{tag}_pinned"]
+        assert np.array_equal(idx[pinned], g[f"{tag}_idx"][pinned])  # == reference off round-off margins
+        assert np.allclose(md, d1, rtol=1e-5, atol=1e-6)        # fp32 direct-form distance
+        assert np.allclose(xd, k[exact] * mask[:, None], atol=0)
+        # fit (reference broadcast semantics: sum over ALL rows / K); fp32 tolerance 2e-5 relative
+        assert np.isclose(sums[0] / k.shape[0], float(g[f"{tag}_fit_masked"]), rtol=2e-5)
+        assert sums[2] == mask.sum()
+    idx, _, _, _ = run_fwd(np.pad(g["tie_x"], ((0, 0), (0, 16))), np.pad(g["tie_k"], ((0, 0), (0, 16))))
+    assert np.array_equal(idx, g["tie_idx"])                    # duplicate codebook rows -> lowest index
+
+
+@pytest.mark.parametrize("n,k,d,seed", [(4544, 256, 128, 0), (36352, 1024, 128, 1), (1000, 200, 64, 2),
+                                        (129, 33, 32, 3), (1, 1, 32, 4), (77, 1024, 128, 5)])
+def test_indices_bit_exact_vs_oracle(n, k, d, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, d, generator=g).numpy()
+    cb = torch.randn(k, d, generator=g).numpy()
+    mask = (torch.rand(n, generator=g) > 0.2).float().numpy()
+    idx, md, xd, sums = run_fwd(x, cb, mask)
+    exact, d1, _ = orc.vq_argmin_exact(x, cb)
+    assert np.array_equal(idx, exact)
+    assert np.allclose(md, d1, rtol=1e-5, atol=1e-6)
+    assert np.array_equal(xd, cb[exact] * mask[:, None])
+    assert np.isclose(sums[0], d1.sum(), rtol=1e-5) and np.isclose(sums[1], (d1 * mask).sum(), rtol=1e-5)
+    assert sums[2] == mask.sum()
+
+
+def test_near_tie_rows_take_the_fp64_path_and_stay_exact():
+    """Encoder-like data (rows sit on top of their code, large common offset): the fp32 gap is
+    inside the round-off bound for many rows; all of them must still equal the exact argmin."""
+    g = torch.Generator().manual_seed(7)
+    n, d, kb = 6000, 128, 512
+    base = torch.randn(n, d, generator=g) * 0.3 + 3.0 * torch.randn(1, d, generator=g)
+    rows = base.repeat(2, 1) + torch.randn(2 * n, d, generator=g) * 1e-4
+    cb = rows[torch.randperm(2 * n, generator=g)][:kb].clone()
+    cb[100] = cb[7]            # exact duplicates too
+    x = base.numpy()
+    idx, md, xd, sums = run_fwd(x, cb.numpy())
+    exact, d1, _ = orc.vq_argmin_exact(x, cb.numpy())
+    assert np.array_equal(idx, exact)
+    assert sums[3] > 0          # the fp64 queue was exercised
+    assert not (idx == 100).any()
+
+
+def test_degenerate_codebook_all_rows_ambiguous():
+    x = torch.randn(300, 64, generator=torch.Generator().manual_seed(1)).numpy()
+    cb = np.zeros((40, 64), dtype=np.float32)
+    idx, md, xd, sums = run_fwd(x, cb)
+    assert (idx == 0).all() and sums[3] == 300
+    assert np.allclose(md, (x.astype(np.float64) ** 2).sum(1), rtol=1e-6)
+
+
+def test_empty_input():
+    idx, md, xd, sums = run_fwd(np.zeros((0, 128), np.float32), np.ones((8, 128), np.float32))
+    assert idx.shape == (0,) and (sums[:3] == 0).all()
+
+
+def test_forward_backward_update_k_match_reference(golden):
+    """Three BottleneckBlock.forward(update_k=True) steps captured from the reference."""
+    from smt_amd import vq
+    g = golden("vq_forward")
+    mask = T(g["mask"])                       # [B,1,T]
+    b, _, t = mask.shape
+    d, kb = 32, 48
+    row_mask = mask.permute(0, 2, 1).reshape(-1).contiguous().cuda()
+    k = dev(g["s0_k_rand_init"]).clone()
+    k_sum, k_elem = k.clone(), torch.ones(kb, device="cuda")
+    for step in range(3):
+        x = dev(T(g[f"s{step}_x"]).permute(0, 2, 1).reshape(-1, d)).requires_grad_(True)
+        k_before = k.clone()
+        x_d, idx, commit, fit = vq.vq_straight_through(x, k_before, row_mask)
+        (x_d.sum() + commit * 3.0).backward()
+        assert np.array_equal(idx.cpu().numpy().reshape(b, t), g[f"s{step}_x_l"])
+        ref_xd = T(g[f"s{step}_x_d"]).permute(0, 2, 1).reshape(-1, d)
+        assert torch.allclose(x_d.detach().cpu(), ref_xd, atol=1e-6)       # x + (x_d - x) rounding
+        assert np.isclose(commit.item(), float(g[f"s{step}_commit"]), rtol=1e-5)
+        assert np.isclose(fit.item(), float(g[f"s{step}_m_fit"]), rtol=2e-5)
+        ref_dx = T(g[f"s{step}_dx"]).permute(0, 2, 1).reshape(-1, d)
+        assert torch.allclose(x.grad.cpu(), ref_dx, atol=1e-6)
+        stats = torch.empty(vq.ema_stats_numel(kb, d), device="cuda")
+        vq.ema_accumulate(x.detach(), idx, row_mask, kb, stats)
+        stats[kb * d + kb:] = dev(g[f"s{step}_k_rand"]).reshape(-1)
+        metrics = vq.ema_apply(k, k_sum, k_elem, stats, stats[kb * d + kb:], float(g["mu"]), float(g["threshold"]))
+        torch.cuda.synchronize()
+        for name, tns in (("k", k), ("k_sum", k_sum), ("k_elem", k_elem)):
+            assert torch.allclose(tns.cpu(), T(g[f"s{step}_{name}"]), atol=1e-5), name
+        for i, mk in enumerate(("entropy", "used_curr", "usage", "dk")):
+            assert np.isclose(metrics[i].item(), float(g[f"s{step}_m_{mk}"]), rtol=1e-4), mk
+
+
+def test_ema_accumulate_matches_dense_onehot():
+    from smt_amd import vq
+    g = torch.Generator().manual_seed(11)
+    n, d, kb = 36352, 128, 1024
+    x = torch.randn(n, d, generator=g)
+    idx = torch.randint(0, kb, (n,), generator=g)
+    mask = (torch.rand(n, generator=g) > 0.1).float()
+    stats = torch.empty(vq.ema_stats_numel(kb, d), device="cuda")
+    vq.ema_accumulate(x.cuda(), idx.cuda(), mask.cuda(), kb, stats)
+    sel = mask != 0
+    ref_sum = torch.zeros(kb, d, dtype=torch.float64).index_add_(0, idx[sel], x[sel].double())
+    ref_cnt = torch.bincount(idx[sel], minlength=kb).double()
+    got = stats.cpu().double()
+    # f32 atomics: order-dependent rounding, ~40 adds per code -> 1e-5 abs on sums of O(10)
+    assert torch.allclose(got[:kb * d].view(kb, d), ref_sum, atol=2e-5)
+    assert torch.equal(got[kb * d:kb * d + kb], ref_cnt)

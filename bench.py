@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Headline benchmark: LJSpeech-shaped utterances/sec of the VQ-VAE train step.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one full train step (train.py:train_step: zero_grad, forward, NaN guard, backward,
+gradient all-reduce, AdamW, scheduler, parameter-EMA hook) on one batch of 32 synthetic
+22.05 kHz clips of 145,408 samples per GPU (BASELINE.json configs[1]: codebook 1024, bf16).
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(REPO, "speech-masters-thesis_amd")
+for _p in (PKG, REPO):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CLIP_LEN = 145408
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+F32_MFMA_PEAK_TFLOPS = 157.3
+BF16_MFMA_PEAK_TFLOPS = 2500.0
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--batch", type=int, default=32, help="clips per GPU")
+    p.add_argument("--model", type=str, default="vqvae_k1024")
+    p.add_argument("--clip_len", type=int, default=CLIP_LEN)
+    p.add_argument("--no_cpu_baseline", action="store_true")
+    p.add_argument("--cpu_clip_len", type=int, default=CLIP_LEN)
+    return p.parse_args()
+
+
+def make_config(args):
+    from utils import config as C
+    cfg = C.merge(C.load(os.path.join(PKG, "configs/models", args.model + ".yaml")),
+                  C.load(os.path.join(PKG, "configs/datasets/synthetic_ljspeech.yaml")),
+                  C.create({"train": {"batch_size": args.batch, "n_gpus": args.gpus, "ema": False,
+                                      "grad_clip_norm": None, "seed": 0, "log_dir": "/tmp/smt_bench"}}))
+    return cfg
+
+
+def synthetic_batches(n_batches, batch, length, rank, device):
+    """Seeded clips of SURVEY 8(d): seed = 1000*rank + step."""
+    from datasets.synthetic import synth_clip
+    out = []
+    for step in range(n_batches):
+        clips = torch.stack([synth_clip(length, (1000 * rank + step) * 64 + i) for i in range(batch)])
+        lens = torch.full((batch,), length, dtype=torch.long)
+        out.append([None, None, None, None, clips.unsqueeze(1).to(device), lens.to(device), None])
+    return out
+
+
+def cpu_baseline(args):
+    """The oracle (CPU restatement of the reference path, oracle/vqvae_oracle.py) timed on this
+    box's host cores on a bounded sample: one clip per step, same clip length and model config."""
+    from oracle import vqvae_oracle as orc
+    from utils import config as C
+    mcfg = C.load(os.path.join(PKG, "configs/models", args.model + ".yaml")).model
+    cfg = orc.VQVAEConfig.from_dict(mcfg.to_dict())
+    threads = torch.get_num_threads()
+    trainer = orc.OracleTrainer(cfg, seed=0)
+    x = orc.synthetic_clip_batch(1, args.cpu_clip_len, 123)
+    lens = torch.tensor([args.cpu_clip_len])
+    trainer.step(x, lens)  # warm-up (codebook init, allocator)
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        trainer.step(x, lens)
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    return {"value": 1.0 / best, "unit": "utterances/s", "cores": threads, "kind": "port",
+            "sample": f"oracle train step (fp32, torch-CPU, {threads} threads), batch 1 x {args.cpu_clip_len} samples, "
+                      f"min of 2 timed steps after 1 warm-up ({best:.1f} s/step)"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group(backend="nccl", init_method="env://")
+
+    from smt_amd import native, profiler
+    native.lib()  # fail loudly if the HIP library is missing
+    from utils.commons import get_model, get_optimizer
+    from utils.train_utils import seed_all_rng
+    import train as trainlib
+
+    cfg = make_config(args)
+    seed_all_rng(cfg.train.seed)
+    model, ema = get_model(cfg, device, rank)
+    optimizer, scheduler = get_optimizer(cfg, model)
+    grad_sync = None
+    if world > 1:
+        from smt_amd.dist import GradSync
+        grad_sync = GradSync(model.parameters())
+    model.train()
+
+    t_start = time.perf_counter()
+    pool = synthetic_batches(min(4, args.steps + args.warmup), args.batch, args.clip_len, rank, device)
+
+    def step(i):
+        return trainlib.train_step(global_step=i, batch=pool[i % len(pool)], config=cfg, model=model, ema=ema,
+                                   optimizer=optimizer, scheduler=scheduler, device=device, rank=rank,
+                                   grad_sync=grad_sync)
+
+    def note(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    note(f"model + {len(pool)} resident batches ready")
+    for i in range(args.warmup):
+        step(i)
+        torch.cuda.synchronize()
+        note(f"warm-up step {i} done")
+    profiler.reset()
+    profiler.enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss_dict, _ = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    profiler.enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank == 0:
+        kernels = profiler.summary()
+        m = cfg.model
+        n_rows = args.batch * (args.clip_len // 128)
+        roofline = None
+        for rec in kernels:
+            if rec["name"] == profiler.DOMINANT:
+                roofline = {k: rec[k] for k in ("bound", "achieved", "peak", "unit", "frac")}
+                roofline.update(kernel=rec["name"], launches=rec["launches"], avg_us=rec["avg_us"], traffic=None)
+        line = {
+            "metric": "LJSpeech utterances/sec per VQ-VAE train step",
+            "value": args.batch * world * args.steps / elapsed,
+            "unit": "utterances/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": m.get("compute_dtype", "fp32"), "data": "synthetic",
+            "config": {"workload": f"configs[1]: models/vqvae codebook={m.l_bins}, batch={args.batch}/GPU, "
+                                   f"{args.clip_len}-sample 22.05 kHz clips, {m.get('compute_dtype')} conv stacks, "
+                                   f"fp32 VQ/losses/AdamW",
+                       "global_batch": args.batch * world, "clip_len": args.clip_len, "codebook": m.l_bins,
+                       "latent_rows_per_gpu": n_rows, "parallelism": f"dp{world}"},
+            "loss": float(loss_dict["loss"].detach()),
+            "roofline": roofline,
+            "kernels": kernels,
+        }
+        note(f"timed region done: {line['value']:.2f} utt/s, {line['ms_per_step']:.1f} ms/step")
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args)
+            note("cpu baseline done")
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -78,6 +78,104 @@ int smt_vq_ema_apply(float* codebook, float* k_sum, float* k_elem, const float* 
                      const float* k_rand, float mu, float threshold, int k_bins, int dim,
                      float* metrics, smt_stream_t stream);
 
+
+/* ------------------------------------------------------------ conv stack ---- */
+/* Counter-based dropout ("dropout" spec).  The reference draws dropout masks from torch's global
+ * RNG (models/vqvae/resnet.py:22,25), which no other device can reproduce; this build defines a
+ * stateless generator so that train mode is parity-testable and backward can recompute the mask:
+ *   keep(i) = ((fmix32((uint32)(i >> 1) * 0x9E3779B1 + key) >> (16 * (i & 1))) & 0xFFFF) >= thresh16
+ * i = linear channels-last index ((b*T + t)*C + c) of the tensor being dropped, fmix32 = MurmurHash3's
+ * finaliser, key = per (step seed, site) 32-bit key, thresh16 = round(p * 65536); kept values are
+ * scaled by drop_scale = 1/(1-p).  oracle/vqvae_oracle.py restates it bit-exactly. */
+
+/* Repack an fp32 torch-layout weight into the [taps][n_out][n_in] operand layout (dtype SMT_F32 /
+ * SMT_BF16):  dst[tap][o][i] = src[o*stride_out + i*stride_in + tap_map[tap]*stride_tap]. */
+int smt_pack_weight(const float* src, void* dst, int dtype, int n_out, int n_in, int taps,
+                    int64_t stride_out, int64_t stride_in, int64_t stride_tap, const int* tap_map,
+                    smt_stream_t stream);
+
+/* One implicit-GEMM convolution over channels-last activations (forward, or a data gradient, which
+ * is the same computation on repacked weights):
+ *   y[b, t*out_stride + out_offset, co] =
+ *       epi( bias[co] + sum_{j<taps} sum_ci pro(x)[b, t*stride + j*dilation - padding, ci] * w[j][co][ci] )
+ *   pro: rows t_in >= lens_in[b] read as 0; if act_in: relu(dropout(.)) (resnet.py:22-26)
+ *   epi: if act_grad: times d relu(dropout(h))/dh at act_grad_src; rows >= lens_out[b] -> 0; + res
+ * Replaces F.conv1d / F.conv_transpose1d of models/vqvae/conv.py:5-18, resnet.py:24,27,205,217 and
+ * their autograd data-gradients.  c_in % 16 == 0 (bf16) or % 8 (f32). */
+typedef struct smt_conv_desc {
+  int dtype;                       /* SMT_F32 | SMT_BF16: x, w, y, res, act_grad_src */
+  int batch, t_in, t_out, t_y;     /* t_out: number of t computed; t_y: rows of y per batch item */
+  int c_in, c_out;
+  int taps, stride, dilation, padding, out_stride, out_offset;
+  int act_in, act_grad;
+  int ld_x, ld_y, ld_res, ld_act;  /* row pitches in elements */
+  uint32_t drop_key, drop_thresh16;
+  float drop_scale;
+  int64_t bs_x, bs_y, bs_res, bs_act;  /* batch strides in elements */
+  const void* x; const void* w; const float* bias; void* y;
+  const void* res; const void* act_grad_src;
+  const int* lens_in; const int* lens_out;
+} smt_conv_desc;
+int smt_conv1d_ntc(const smt_conv_desc* desc, smt_stream_t stream);
+
+/* Weight (+ bias) gradient of the same convolution:
+ *   dw[j][co][ci] = sum_{b,t} dy[b, t*out_stride + out_offset, co] * pro(x)[b, t*stride + j*dil - pad, ci]
+ *   db[co]        = sum_{b,t} dy[b, ., co]                                   (if dbias != NULL)
+ * written in fp32 to dweight[o*stride_out + i*stride_in + tap_map[tap]*stride_tap] (torch layout).
+ * `desc` is the forward descriptor with y := dy (w, bias, res, act_grad unused). */
+size_t smt_conv1d_wgrad_workspace_bytes(const smt_conv_desc* desc);
+int smt_conv1d_wgrad(const smt_conv_desc* desc, float* dweight, int64_t stride_out, int64_t stride_in,
+                     int64_t stride_tap, const int* tap_map, float* dbias, void* workspace,
+                     size_t workspace_bytes, smt_stream_t stream);
+
+/* sum_d tanh(t_d) * softmax_d(s_d) over `depth` branches laid side by side along the channel axis
+ * (z[.., d*2w + c] = t_d, z[.., d*2w + w + c] = s_d) -- GatedHiFiBlock.forward, resnet.py:229-237. */
+int smt_gate_mix_fwd(const void* z, void* g, int dtype, int64_t rows, int width, int depth, int ld_z, int ld_g,
+                     smt_stream_t stream);
+int smt_gate_mix_bwd(const void* z, const void* dg, void* dz, int dtype, int64_t rows, int width, int depth,
+                     int ld_z, int ld_g, int ld_dz, smt_stream_t stream);
+
+/* The encoder's first convolution (C_in = 1; conv.py:61 with input_emb_width = 1): x fp32 [B, t_in],
+ * weight fp32 [c_out][taps], y [B, t_out, c_out] in `dtype`; rows >= lens[b] of x read as 0. */
+int smt_conv_in_fwd(const float* x, const float* weight, const float* bias, const int* lens, void* y, int dtype,
+                    int batch, int t_in, int t_out, int c_out, int taps, int stride, int padding,
+                    smt_stream_t stream);
+size_t smt_conv_in_wgrad_workspace_bytes(int batch, int t_out, int c_out);
+int smt_conv_in_wgrad(const float* x, const void* dy, const int* lens, float* dweight, float* dbias, int dtype,
+                      int batch, int t_in, int t_out, int c_out, int taps, int stride, int padding, void* workspace,
+                      size_t workspace_bytes, smt_stream_t stream);
+
+/* The decoder's final 1x1 projection to one channel on masked rows (encdec.py:61,82):
+ * y[b,t] = bias + sum_c x[b,t,c]*mask*w[c], y fp32 [B, t].  bwd writes dx (dtype) and fp32 dw/db. */
+int smt_conv_out_fwd(const void* x, const float* weight, const float* bias, const int* lens, float* y, int dtype,
+                     int batch, int t, int c_in, smt_stream_t stream);
+size_t smt_conv_out_bwd_workspace_bytes(int batch, int t, int c_in);
+int smt_conv_out_bwd(const void* x, const float* weight, const int* lens, const float* dy, void* dx, float* dweight,
+                     float* dbias, int dtype, int batch, int t, int c_in, void* workspace, size_t workspace_bytes,
+                     smt_stream_t stream);
+
+/* ------------------------------------------------------------- spectral ---- */
+/* Windowed STFT magnitude (STFT.forward, datasets/transforms.py:108-123): reflect padding
+ * (n_fft - hop)/2, frame every `hop`, window[n_fft] (Hann centre-padded), bins 0..n_fft/2.
+ *   x [batch, t] f32;  window [n_fft] f32;  twiddle [n_fft/2] complex f32 = exp(-2 pi i m / n_fft)
+ *   mag [batch, n_fft/2+1, frames] f32, frames = smt_stft_num_frames(t, n_fft, hop)
+ * n_fft in {256, 512, 1024, 2048}. */
+int smt_stft_num_frames(int t, int n_fft, int hop);
+int smt_stft_magnitude(const float* x, const float* window, const float* twiddle, float* mag, int batch, int t,
+                       int n_fft, int hop, smt_stream_t stream);
+/* Fused log-mel (MelSpectrogram.forward, transforms.py:61-65): mel [batch, n_mels, frames] =
+ * log(max(mel_basis @ |STFT|, 1e-5)); band[2m], band[2m+1] = first / one-past-last non-zero bin of row m. */
+int smt_melspec(const float* x, const float* window, const float* twiddle, const float* mel_basis, const int* band,
+                float* mel, int batch, int t, int n_fft, int hop, int n_mels, smt_stream_t stream);
+/* One resolution of MultiResolutionSpectralLoss (models/vqvae/losses.py:39-55) without materialising
+ * the spectra.  fwd: partial [batch, frames, 2] = per-frame sums of ((|Y|-|Yh|) m)^2 and
+ * ((log|Y| - log|Yh|) m)^2 (clamp 1e-5), m = frame mask from lens (losses.py:33-37).
+ * bwd: dyh [batch, t] += adjoint of dL/dYh with coef [batch, 2] = upstream * 1/(2 B sqrt(S)) per term. */
+int smt_stft_loss_fwd(const float* y, const float* yh, const int* lens, const float* window, const float* twiddle,
+                      float* partial, int batch, int t, int n_fft, int hop, smt_stream_t stream);
+int smt_stft_loss_bwd(const float* y, const float* yh, const int* lens, const float* window, const float* twiddle,
+                      const float* coef, float* dyh, int batch, int t, int n_fft, int hop, smt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -651,15 +651,16 @@ def dropout_site_key(seed: int, site: int) -> int:
 
 
 def dropout_keep_ntc(seed: int, site: int, b: int, t: int, c: int, p: float) -> np.ndarray:
-    """keep[b, t, c] (bool) for linear channels-last index i = (b*T + t)*C + c:
-    keep iff fmix32(i * 0x9E3779B1 + key) >= floor(p * 2^32)."""
+    """keep[b, t, c] (bool) for linear channels-last index i = (b*T + t)*C + c (include/smt_hip.h
+    "dropout"): 16 random bits per element, two elements per hash:
+        h = fmix32((uint32)(i >> 1) * 0x9E3779B1 + key);  keep iff ((h >> 16*(i&1)) & 0xFFFF) >= round(p*65536)."""
     key = np.uint32(dropout_site_key(seed, site))
     i = np.arange(b * t * c, dtype=np.uint64)
-    h = ((i * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-    h = (h + key).astype(np.uint32)
-    h = _fmix32(h)
-    thresh = np.uint32(int(p * 4294967296.0))
-    return (h >= thresh).reshape(b, t, c)
+    h = (((i >> np.uint64(1)) * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    h = _fmix32((h + key).astype(np.uint32))
+    bits = (h >> (np.uint32(16) * (i & np.uint64(1)).astype(np.uint32))) & np.uint32(0xFFFF)
+    thresh = np.uint32(int(round(p * 65536.0)))
+    return (bits >= thresh).reshape(b, t, c)
 
 
 def make_counter_dropout(seed: int, p: float, site_ids: Dict[str, int]) -> DropFn:

@@ -1,0 +1,329 @@
+// Channels-last 1-D convolution as an implicit GEMM on the gfx950 matrix cores.
+//
+// Replaces F.conv1d / F.conv_transpose1d under MaskedConv1d, MaskedConvTranspose1d, ResLayer and
+// GatedHiFiBlock of the reference (models/vqvae/conv.py:5-18, resnet.py:16-36, 184-241) -- forward
+// and data-gradient (the data-gradient of a convolution is a convolution with repacked weights).
+//
+//   y[b, t*os + oo, co] = epi( sum_j sum_ci pro(x)[b, t*stride + j*dil - pad, ci] * w[j][co][ci] )
+//
+// Activations are [B, T, C] with an explicit row pitch, so channel slices of a wider tensor are
+// operands without copies.  One workgroup (4 waves, 2x2) computes BM output rows x BN output
+// channels:  the haloed input tile is staged ONCE into LDS (the prologue -- row mask, ReLU,
+// counter-based dropout -- is applied while staging, once per element, not once per tap) and every
+// tap reads it at a row offset; weight chunks [BN x KC] stream through a double buffer.
+//   bf16: v_mfma_f32_32x32x16_bf16, fp32 accumulate.   fp32: v_mfma_f32_32x32x2_f32 (exact fp32 fma
+//   chains; the parity path).  Both read 16-byte fragments with ds_read_b128 from rows padded by
+//   16 B (conflict-free, cdna guide G4).
+// The accumulator tile goes back through LDS so that the epilogue (bias, activation gradient, row
+// mask, residual) and the stores are fully coalesced 16-byte accesses.
+#include <algorithm>
+
+#include "smt_common.h"
+#include "conv_common.h"
+
+namespace smt {
+
+struct ConvArgs {
+  const void* x; const void* w; const float* bias; void* y; const void* res; const void* gate_h;
+  const int* lens_in; const int* lens_out;
+  long long x_bs, y_bs, res_bs, gh_bs;  // batch strides (elements)
+  int ldx, ldy, ldr, ldgh;              // row pitches (elements)
+  int B, Tin, Tout, Cin, Cout;          // Tout = output rows PER LAUNCH INDEX t (before os/oo)
+  int taps, stride, dil, pad;
+  int out_stride, out_offset, Ty;       // output row = t*out_stride + out_offset, Ty rows in y per batch
+  int pro_act, epi_act;                 // relu+dropout prologue / its derivative as epilogue
+  unsigned drop_key, drop_thresh16; float drop_scale;
+  int tiles_per_batch;
+};
+
+template <typename T>
+__device__ __forceinline__ void mma_step(const T* a, const T* b, f32x16& acc);
+template <>
+__device__ __forceinline__ void mma_step<__bf16>(const __bf16* a, const __bf16* b, f32x16& acc) {
+  bf16x8 av = *reinterpret_cast<const bf16x8*>(a);
+  bf16x8 bv = *reinterpret_cast<const bf16x8*>(b);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_step<float>(const float* a, const float* b, f32x16& acc) {
+  f32x4 av = *reinterpret_cast<const f32x4*>(a);
+  f32x4 bv = *reinterpret_cast<const f32x4*>(b);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+}
+
+// BN = 128 (NW = 2 column tiles per wave) or 64 (NW = 1); waves 2 (rows) x 2 (cols)
+template <typename T, int BN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
+  constexpr int EPV = Tr<T>::EPV, CCH = Tr<T>::CCH, KC = Tr<T>::KC, BM = Tr<T>::BM;
+  constexpr int MW = BM / 64;           // 32-row tiles per wave (bf16: 2, fp32: 1)
+  constexpr int NW = BN / 64;           // 32-col tiles per wave
+  constexpr int PITCH_W = KC + EPV;
+  constexpr int PITCH_C = BN + EPV;
+  constexpr int WVEC = BN * KC / EPV;   // 16-byte vectors per weight chunk
+  constexpr int WST = WVEC / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.x / p.tiles_per_batch;
+  const int t0 = (blockIdx.x % p.tiles_per_batch) * BM;
+  const int n0 = blockIdx.y * BN;
+
+  const int rows_in = (BM - 1) * p.stride + (p.taps - 1) * p.dil + 1;
+  const int cch_max = min(p.Cin, CCH);
+  const int pitch_a = cch_max + EPV;
+  T* lds_a = reinterpret_cast<T*>(smem);
+  const size_t a_bytes = align_up((size_t)max(rows_in * pitch_a, BM * PITCH_C) * sizeof(T), 16);
+  T* lds_w = reinterpret_cast<T*>(smem + a_bytes);
+  T* lds_c = lds_a;
+
+  const T* xg = reinterpret_cast<const T*>(p.x) + (long long)b * p.x_bs;
+  const T* wg = reinterpret_cast<const T*>(p.w);
+  const int len_in = p.lens_in ? min(p.lens_in[b], p.Tin) : p.Tin;
+  const int tin0 = t0 * p.stride - p.pad;
+
+  f32x16 acc[MW][NW];
+#pragma unroll
+  for (int i = 0; i < MW; ++i)
+#pragma unroll
+    for (int n = 0; n < NW; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][n][e] = 0.f;
+
+  Vec<T, EPV> wst[WST];
+  auto w_load = [&](int j, int ci0) {  // chunk rows co = n0.., cols ci = ci0..ci0+KC
+#pragma unroll
+    for (int s = 0; s < WST; ++s) {
+      int f = tid + 256 * s;
+      int co = f / (KC / EPV), cv = f % (KC / EPV);
+      int ci = ci0 + cv * EPV;
+      Vec<T, EPV> v;
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) v.v[e] = (T)0.f;
+      if (n0 + co < p.Cout && ci < p.Cin)
+        v = *reinterpret_cast<const Vec<T, EPV>*>(wg + ((size_t)j * p.Cout + n0 + co) * p.Cin + ci);
+      wst[s] = v;
+    }
+  };
+  auto w_store = [&](int buf) {
+#pragma unroll
+    for (int s = 0; s < WST; ++s) {
+      int f = tid + 256 * s;
+      int co = f / (KC / EPV), cv = f % (KC / EPV);
+      *reinterpret_cast<Vec<T, EPV>*>(lds_w + (size_t)buf * BN * PITCH_W + co * PITCH_W + cv * EPV) = wst[s];
+    }
+  };
+
+  for (int cc = 0; cc < p.Cin; cc += CCH) {
+    const int cch = min(CCH, p.Cin - cc);
+    __syncthreads();  // previous chunk's readers are done with lds_a / lds_w
+    // ---- stage the haloed input tile (this channel chunk), prologue applied once per element
+    const int vpr = cch / EPV;
+    for (int f = tid; f < rows_in * vpr; f += 256) {
+      const int row = f / vpr, cv = f % vpr;
+      const int tin = tin0 + row;
+      Vec<T, EPV> v;
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) v.v[e] = (T)0.f;
+      if (tin >= 0 && tin < len_in) {
+        v = *reinterpret_cast<const Vec<T, EPV>*>(xg + (long long)tin * p.ldx + cc + cv * EPV);
+        if (p.pro_act) {
+          const unsigned long long base = ((unsigned long long)b * p.Tin + tin) * p.Cin + cc + cv * EPV;
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) {
+            float fv = (float)v.v[e];
+            bool keep = drop_keep(base + e, p.drop_key, p.drop_thresh16);
+            fv = (keep && fv > 0.f) ? fv * p.drop_scale : 0.f;
+            v.v[e] = (T)fv;
+          }
+        }
+      }
+      *reinterpret_cast<Vec<T, EPV>*>(lds_a + row * pitch_a + cv * EPV) = v;
+    }
+    // ---- K loop: taps x K-chunks, weight chunks double-buffered
+    const int nkc = (cch + KC - 1) / KC;
+    const int nsteps = p.taps * nkc;
+    w_load(0, cc);
+    w_store(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+      const int j = s / nkc, kc = s % nkc;
+      const int buf = s & 1;
+      if (s + 1 < nsteps) w_load((s + 1) / nkc, cc + ((s + 1) % nkc) * KC);
+      const int kvalid = min(KC, cch - kc * KC);
+      const T* abase = lds_a + (wm * (BM / 2) * p.stride + j * p.dil + r * p.stride) * pitch_a + kc * KC + hh * EPV;
+      const T* bbase = lds_w + (size_t)buf * BN * PITCH_W + (wn * (BN / 2) + r) * PITCH_W + hh * EPV;
+      for (int kk = 0; kk < kvalid; kk += 2 * EPV) {
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+          for (int n = 0; n < NW; ++n)
+            mma_step<T>(abase + i * 32 * p.stride * pitch_a + kk, bbase + n * 32 * PITCH_W + kk, acc[i][n]);
+      }
+      if (s + 1 < nsteps) w_store(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- accumulators -> LDS (element type T) -> coalesced epilogue
+#pragma unroll
+  for (int i = 0; i < MW; ++i)
+#pragma unroll
+    for (int n = 0; n < NW; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int row = wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        int col = wn * (BN / 2) + n * 32 + r;
+        // bias joins in fp32 before the (single, for residual-free layers) rounding to T
+        float bv = (p.bias && n0 + col < p.Cout) ? p.bias[n0 + col] : 0.f;
+        lds_c[row * PITCH_C + col] = (T)(acc[i][n][e] + bv);
+      }
+  __syncthreads();
+  T* yg = reinterpret_cast<T*>(p.y) + (long long)b * p.y_bs;
+  const T* rg = p.res ? reinterpret_cast<const T*>(p.res) + (long long)b * p.res_bs : nullptr;
+  const T* hg = p.epi_act ? reinterpret_cast<const T*>(p.gate_h) + (long long)b * p.gh_bs : nullptr;
+  const int len_out = p.lens_out ? p.lens_out[b] : 0x7fffffff;
+  constexpr int CV = BN / EPV;
+  for (int f = tid; f < BM * CV; f += 256) {
+    const int row = f / CV, cv = f % CV;
+    const int t = t0 + row, col = n0 + cv * EPV;
+    if (t >= p.Tout || col >= p.Cout) continue;
+    const int ty = t * p.out_stride + p.out_offset;
+    if (ty >= p.Ty) continue;
+    Vec<T, EPV> c = *reinterpret_cast<const Vec<T, EPV>*>(lds_c + row * PITCH_C + cv * EPV);
+    float o[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) o[e] = (float)c.v[e];
+    if (p.epi_act) {
+      Vec<T, EPV> h = *reinterpret_cast<const Vec<T, EPV>*>(hg + (long long)ty * p.ldgh + col);
+      const unsigned long long base = ((unsigned long long)b * p.Ty + ty) * p.Cout + col;
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) {
+        bool keep = drop_keep(base + e, p.drop_key, p.drop_thresh16);
+        o[e] = (keep && (float)h.v[e] > 0.f) ? o[e] * p.drop_scale : 0.f;
+      }
+    }
+    if (ty >= len_out) {
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) o[e] = 0.f;
+    }
+    if (rg) {
+      Vec<T, EPV> rv = *reinterpret_cast<const Vec<T, EPV>*>(rg + (long long)ty * p.ldr + col);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) o[e] += (float)rv.v[e];
+    }
+    Vec<T, EPV> out;
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) out.v[e] = (T)o[e];
+    *reinterpret_cast<Vec<T, EPV>*>(yg + (long long)ty * p.ldy + col) = out;
+  }
+}
+
+template <typename T>
+static size_t conv_gemm_lds_bytes(const ConvArgs& p, int BN) {
+  constexpr int EPV = Tr<T>::EPV, CCH = Tr<T>::CCH, KC = Tr<T>::KC, BM = Tr<T>::BM;
+  int rows_in = (BM - 1) * p.stride + (p.taps - 1) * p.dil + 1;
+  int pitch_a = std::min(p.Cin, CCH) + EPV;
+  size_t a = align_up((size_t)std::max(rows_in * pitch_a, BM * (BN + EPV)) * sizeof(T), 16);
+  return a + (size_t)2 * BN * (KC + EPV) * sizeof(T);
+}
+
+template <typename T>
+static int launch_conv_gemm(ConvArgs p, hipStream_t stream) {
+  constexpr int BM = Tr<T>::BM;
+  const int BN = (p.Cout > 64) ? 128 : 64;
+  p.tiles_per_batch = (p.Tout + BM - 1) / BM;
+  dim3 grid((unsigned)(p.tiles_per_batch * p.B), (unsigned)((p.Cout + BN - 1) / BN));
+  size_t lds = conv_gemm_lds_bytes<T>(p, BN);
+  SMT_CHECK_ARG(lds <= 160 * 1024, "conv_gemm: tile needs %zu B of LDS (taps=%d dil=%d stride=%d Cin=%d)", lds,
+                p.taps, p.dil, p.stride, p.Cin);
+  if (BN == 128) {
+    static bool attr128 = false;
+    if (!attr128) {
+      (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<T, 128>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024);
+      attr128 = true;
+    }
+    conv_gemm_kernel<T, 128><<<grid, 256, lds, stream>>>(p);
+  } else {
+    static bool attr64 = false;
+    if (!attr64) {
+      (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<T, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024);
+      attr64 = true;
+    }
+    conv_gemm_kernel<T, 64><<<grid, 256, lds, stream>>>(p);
+  }
+  SMT_CHECK_LAUNCH("conv_gemm");
+  return 0;
+}
+
+// ---- weight repacking: dst[tap][o][i] (act dtype) = src[o*so + i*si + jmap[tap]*sj] (fp32) ------------
+struct PackArgs {
+  const float* src; void* dst; int O, I, taps; long long so, si, sj; int jmap[16];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_kernel(PackArgs p) {
+  const long long total = (long long)p.taps * p.O * p.I;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    int i = (int)(e % p.I);
+    int o = (int)((e / p.I) % p.O);
+    int tap = (int)(e / ((long long)p.I * p.O));
+    reinterpret_cast<T*>(p.dst)[e] = (T)p.src[o * p.so + i * p.si + p.jmap[tap] * p.sj];
+  }
+}
+
+}  // namespace smt
+
+using namespace smt;
+
+extern "C" int smt_pack_weight(const float* src, void* dst, int dtype, int n_out, int n_in, int taps,
+                               int64_t stride_out, int64_t stride_in, int64_t stride_tap, const int* tap_map,
+                               smt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SMT_CHECK_ARG(src && dst && tap_map, "smt_pack_weight: null pointer");
+  SMT_CHECK_ARG(taps >= 1 && taps <= 16, "smt_pack_weight: taps must be in [1, 16]");
+  PackArgs p;
+  p.src = src; p.dst = dst; p.O = n_out; p.I = n_in; p.taps = taps;
+  p.so = stride_out; p.si = stride_in; p.sj = stride_tap;
+  for (int t = 0; t < taps; ++t) p.jmap[t] = tap_map[t];
+  long long total = (long long)taps * n_out * n_in;
+  unsigned grid = (unsigned)std::min<long long>(1024, (total + 255) / 256);
+  if (dtype == SMT_BF16) pack_weight_kernel<__bf16><<<grid, 256, 0, stream>>>(p);
+  else if (dtype == SMT_F32) pack_weight_kernel<float><<<grid, 256, 0, stream>>>(p);
+  else SMT_CHECK_ARG(false, "smt_pack_weight: bad dtype %d", dtype);
+  SMT_CHECK_LAUNCH("pack_weight");
+  return 0;
+}
+
+extern "C" int smt_conv1d_ntc(const smt_conv_desc* d, smt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SMT_CHECK_ARG(d && d->x && d->w && d->y, "smt_conv1d_ntc: null pointer");
+  const int epv = d->dtype == SMT_BF16 ? 8 : 4;
+  SMT_CHECK_ARG(d->dtype == SMT_BF16 || d->dtype == SMT_F32, "smt_conv1d_ntc: bad dtype");
+  SMT_CHECK_ARG(d->c_in % (2 * epv) == 0, "smt_conv1d_ntc: c_in=%d must be a multiple of %d", d->c_in, 2 * epv);
+  SMT_CHECK_ARG(d->c_out % epv == 0, "smt_conv1d_ntc: c_out=%d must be a multiple of %d", d->c_out, epv);
+  SMT_CHECK_ARG(d->ld_x % epv == 0 && d->ld_y % epv == 0 && (!d->res || d->ld_res % epv == 0) &&
+                    (!d->act_grad_src || d->ld_act % epv == 0),
+                "smt_conv1d_ntc: row pitches must keep 16-byte alignment");
+  SMT_CHECK_ARG(d->taps >= 1 && d->stride >= 1 && d->dilation >= 1 && d->out_stride >= 1, "smt_conv1d_ntc: bad geometry");
+  SMT_CHECK_ARG(!d->act_grad || d->act_grad_src, "smt_conv1d_ntc: act_grad needs act_grad_src");
+  if (d->batch == 0 || d->t_out == 0) return 0;
+  ConvArgs p;
+  p.x = d->x; p.w = d->w; p.bias = d->bias; p.y = d->y; p.res = d->res; p.gate_h = d->act_grad_src;
+  p.lens_in = d->lens_in; p.lens_out = d->lens_out;
+  p.x_bs = d->bs_x; p.y_bs = d->bs_y; p.res_bs = d->bs_res; p.gh_bs = d->bs_act;
+  p.ldx = d->ld_x; p.ldy = d->ld_y; p.ldr = d->ld_res; p.ldgh = d->ld_act;
+  p.B = d->batch; p.Tin = d->t_in; p.Tout = d->t_out; p.Cin = d->c_in; p.Cout = d->c_out;
+  p.taps = d->taps; p.stride = d->stride; p.dil = d->dilation; p.pad = d->padding;
+  p.out_stride = d->out_stride; p.out_offset = d->out_offset; p.Ty = d->t_y;
+  p.pro_act = d->act_in; p.epi_act = d->act_grad;
+  p.drop_key = d->drop_key; p.drop_thresh16 = d->drop_thresh16; p.drop_scale = d->drop_scale;
+  p.tiles_per_batch = 0;
+  if (d->dtype == SMT_BF16) return launch_conv_gemm<__bf16>(p, stream);
+  return launch_conv_gemm<float>(p, stream);
+}

@@ -1,0 +1,405 @@
+// The HBM-bound members of the conv stack (no matrix-core work):
+//   * gate_mix        sum_d tanh(t_d) * softmax_d(s_d)         (resnet.py:229-237) fwd + bwd
+//   * conv_in         the encoder's first conv, C_in = 1        (conv.py:61, k=2s stride s) fwd + wgrad
+//   * conv_out        the decoder's final 1x1 conv, C_out = 1   (encdec.py:61,82) fwd + bwd
+// All are one pass over their operands with 16-byte accesses along the channel axis.
+#include <algorithm>
+
+#include "conv_common.h"
+
+namespace smt {
+
+constexpr int GM_MAX_DEPTH = 8;
+
+// ------------------------------------------------------------------ gate_mix ----
+// z: [rows, depth*2*w] (pitch ldz): branch d has t at [d*2w, d*2w+w), s at [d*2w+w, (d+1)*2w)
+template <typename T>
+__global__ __launch_bounds__(256) void gate_mix_fwd_kernel(const T* __restrict__ z, T* __restrict__ g, long long rows,
+                                                           int w, int depth, int ldz, int ldg) {
+  constexpr int EPV = Tr<T>::EPV;
+  const int vpr = w / EPV;
+  const long long total = rows * vpr;
+  for (long long f = (long long)blockIdx.x * 256 + threadIdx.x; f < total; f += (long long)gridDim.x * 256) {
+    const long long row = f / vpr;
+    const int c = (int)(f % vpr) * EPV;
+    float tv[GM_MAX_DEPTH][EPV], sv[GM_MAX_DEPTH][EPV];
+#pragma unroll
+    for (int d = 0; d < GM_MAX_DEPTH; ++d) {
+      if (d < depth) {
+        Vec<T, EPV> a = *reinterpret_cast<const Vec<T, EPV>*>(z + row * ldz + d * 2 * w + c);
+        Vec<T, EPV> b = *reinterpret_cast<const Vec<T, EPV>*>(z + row * ldz + d * 2 * w + w + c);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) { tv[d][e] = (float)a.v[e]; sv[d][e] = (float)b.v[e]; }
+      }
+    }
+    Vec<T, EPV> out;
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      float m = -INFINITY;
+#pragma unroll
+      for (int d = 0; d < GM_MAX_DEPTH; ++d) if (d < depth) m = fmaxf(m, sv[d][e]);
+      float den = 0.f, num = 0.f;
+#pragma unroll
+      for (int d = 0; d < GM_MAX_DEPTH; ++d) if (d < depth) {
+        float ex = __expf(sv[d][e] - m);
+        den += ex;
+        num += ex * tanhf(tv[d][e]);
+      }
+      out.v[e] = (T)(num / den);
+    }
+    *reinterpret_cast<Vec<T, EPV>*>(g + row * ldg + c) = out;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gate_mix_bwd_kernel(const T* __restrict__ z, const T* __restrict__ dg,
+                                                           T* __restrict__ dz, long long rows, int w, int depth,
+                                                           int ldz, int ldg, int lddz) {
+  constexpr int EPV = Tr<T>::EPV;
+  const int vpr = w / EPV;
+  const long long total = rows * vpr;
+  for (long long f = (long long)blockIdx.x * 256 + threadIdx.x; f < total; f += (long long)gridDim.x * 256) {
+    const long long row = f / vpr;
+    const int c = (int)(f % vpr) * EPV;
+    float th[GM_MAX_DEPTH][EPV], sm[GM_MAX_DEPTH][EPV];
+#pragma unroll
+    for (int d = 0; d < GM_MAX_DEPTH; ++d) {
+      if (d < depth) {
+        Vec<T, EPV> a = *reinterpret_cast<const Vec<T, EPV>*>(z + row * ldz + d * 2 * w + c);
+        Vec<T, EPV> b = *reinterpret_cast<const Vec<T, EPV>*>(z + row * ldz + d * 2 * w + w + c);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) { th[d][e] = tanhf((float)a.v[e]); sm[d][e] = (float)b.v[e]; }
+      }
+    }
+    Vec<T, EPV> gv = *reinterpret_cast<const Vec<T, EPV>*>(dg + row * ldg + c);
+    Vec<T, EPV> dt[GM_MAX_DEPTH], ds[GM_MAX_DEPTH];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      float m = -INFINITY;
+#pragma unroll
+      for (int d = 0; d < GM_MAX_DEPTH; ++d) if (d < depth) m = fmaxf(m, sm[d][e]);
+      float den = 0.f;
+#pragma unroll
+      for (int d = 0; d < GM_MAX_DEPTH; ++d) if (d < depth) { sm[d][e] = __expf(sm[d][e] - m); den += sm[d][e]; }
+      const float go = (float)gv.v[e];
+      float dot = 0.f;
+#pragma unroll
+      for (int d = 0; d < GM_MAX_DEPTH; ++d) if (d < depth) { sm[d][e] /= den; dot += sm[d][e] * th[d][e]; }
+#pragma unroll
+      for (int d = 0; d < GM_MAX_DEPTH; ++d) if (d < depth) {
+        dt[d].v[e] = (T)(go * sm[d][e] * (1.f - th[d][e] * th[d][e]));
+        ds[d].v[e] = (T)(go * sm[d][e] * (th[d][e] - dot));
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < GM_MAX_DEPTH; ++d) if (d < depth) {
+      *reinterpret_cast<Vec<T, EPV>*>(dz + row * lddz + d * 2 * w + c) = dt[d];
+      *reinterpret_cast<Vec<T, EPV>*>(dz + row * lddz + d * 2 * w + w + c) = ds[d];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ conv_in -----
+// y[b,t,co] = bias[co] + sum_j x[b, t*s + j - pad] * w[co][j];  x fp32 [B,Tin], rows >= lens[b] read 0
+template <typename T>
+__global__ __launch_bounds__(256) void conv_in_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, const int* __restrict__ lens,
+                                                          T* __restrict__ y, int B, int Tin, int Tout, int C, int taps,
+                                                          int stride, int pad) {
+  constexpr int EPV = Tr<T>::EPV;
+  const int vpr = C / EPV;
+  const long long total = (long long)B * Tout * vpr;
+  for (long long f = (long long)blockIdx.x * 256 + threadIdx.x; f < total; f += (long long)gridDim.x * 256) {
+    const int cv = (int)(f % vpr);
+    const long long bt = f / vpr;
+    const int t = (int)(bt % Tout), b = (int)(bt / Tout);
+    const int len = lens ? min(lens[b], Tin) : Tin;
+    float o[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) o[e] = bias[cv * EPV + e];
+    for (int j = 0; j < taps; ++j) {
+      const int tin = t * stride + j - pad;
+      const float xv = (tin >= 0 && tin < len) ? x[(long long)b * Tin + tin] : 0.f;
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) o[e] = fmaf(xv, w[(cv * EPV + e) * taps + j], o[e]);
+    }
+    Vec<T, EPV> out;
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) out.v[e] = (T)o[e];
+    *reinterpret_cast<Vec<T, EPV>*>(y + bt * C + cv * EPV) = out;
+  }
+}
+
+// partial[wg][co][taps+1]: thread (q = tid/C', co) accumulates over its rows, LDS-reduced over q
+template <typename T>
+__global__ __launch_bounds__(256) void conv_in_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ dy,
+                                                            const int* __restrict__ lens, float* __restrict__ partial,
+                                                            int B, int Tin, int Tout, int C, int taps, int stride,
+                                                            int pad, long long rows_per_wg) {
+  __shared__ float red[256 * 9];
+  const int co = threadIdx.x % C, q = threadIdx.x / C, nq = 256 / C;
+  const long long r0 = (long long)blockIdx.x * rows_per_wg;
+  const long long r1 = min((long long)B * Tout, r0 + rows_per_wg);
+  float acc[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) acc[j] = 0.f;
+  if (q < nq) {
+    for (long long bt = r0 + q; bt < r1; bt += nq) {
+      const int t = (int)(bt % Tout), b = (int)(bt / Tout);
+      const int len = lens ? min(lens[b], Tin) : Tin;
+      const float g = (float)dy[bt * C + co];
+      acc[8] += g;
+      for (int j = 0; j < taps; ++j) {
+        const int tin = t * stride + j - pad;
+        const float xv = (tin >= 0 && tin < len) ? x[(long long)b * Tin + tin] : 0.f;
+        acc[j] = fmaf(g, xv, acc[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 9; ++j) red[threadIdx.x * 9 + j] = acc[j];
+  __syncthreads();
+  if (threadIdx.x < C) {
+    for (int j = 0; j < 9; ++j) {
+      float s = 0.f;
+      for (int qq = 0; qq < nq; ++qq) s += red[(qq * C + threadIdx.x) * 9 + j];
+      partial[((size_t)blockIdx.x * C + threadIdx.x) * 9 + j] = s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void conv_in_wgrad_reduce_kernel(const float* __restrict__ partial, int n_wg, int C,
+                                                                   int taps, float* __restrict__ dw,
+                                                                   float* __restrict__ db) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= C * 9) return;
+  const int co = e / 9, j = e % 9;
+  if (j >= taps && j != 8) return;
+  float s = 0.f;
+  for (int g = 0; g < n_wg; ++g) s += partial[((size_t)g * C + co) * 9 + j];
+  if (j == 8) db[co] = s; else dw[co * taps + j] = s;
+}
+
+// ------------------------------------------------------------------ conv_out ----
+// y[b,t] = bias + sum_c x[b,t,c]*m*w[c];  LPR lanes share a row
+template <typename T>
+__global__ __launch_bounds__(256) void conv_out_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, const int* __restrict__ lens,
+                                                           float* __restrict__ y, int B, int Tt, int C) {
+  constexpr int EPV = Tr<T>::EPV;
+  const int lpr = C / EPV;  // lanes per row (power of two, <= 64)
+  const int rows_per_blk = 256 / lpr;
+  const int lane_in_row = threadIdx.x % lpr;
+  const long long total = (long long)B * Tt;
+  for (long long row = (long long)blockIdx.x * rows_per_blk + threadIdx.x / lpr; row < total;
+       row += (long long)gridDim.x * rows_per_blk) {
+    const int t = (int)(row % Tt), b = (int)(row / Tt);
+    const bool valid = !lens || t < lens[b];
+    float s = 0.f;
+    if (valid) {
+      Vec<T, EPV> v = *reinterpret_cast<const Vec<T, EPV>*>(x + row * C + lane_in_row * EPV);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) s = fmaf((float)v.v[e], w[lane_in_row * EPV + e], s);
+    }
+    for (int o = lpr >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane_in_row == 0) y[row] = s + bias[0];
+  }
+}
+
+// dx[b,t,c] = dy[b,t]*m*w[c];  partial dw/db per workgroup
+template <typename T>
+__global__ __launch_bounds__(256) void conv_out_bwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                           const int* __restrict__ lens, const float* __restrict__ dy,
+                                                           T* __restrict__ dx, float* __restrict__ partial, int B,
+                                                           int Tt, int C, long long rows_per_wg) {
+  constexpr int EPV = Tr<T>::EPV;
+  __shared__ float red[256 * 9];
+  const int lpr = C / EPV;
+  const int rows_per_it = 256 / lpr;
+  const int lane_in_row = threadIdx.x % lpr;
+  const long long r0 = (long long)blockIdx.x * rows_per_wg;
+  const long long r1 = min((long long)B * Tt, r0 + rows_per_wg);
+  float acc[EPV], accb = 0.f;
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) acc[e] = 0.f;
+  float wv[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) wv[e] = w[lane_in_row * EPV + e];
+  for (long long row = r0 + threadIdx.x / lpr; row < r1; row += rows_per_it) {
+    const int t = (int)(row % Tt), b = (int)(row / Tt);
+    const bool valid = !lens || t < lens[b];
+    const float g = dy[row];
+    Vec<T, EPV> out;
+    if (valid) {
+      Vec<T, EPV> v = *reinterpret_cast<const Vec<T, EPV>*>(x + row * C + lane_in_row * EPV);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) { acc[e] = fmaf(g, (float)v.v[e], acc[e]); out.v[e] = (T)(g * wv[e]); }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) out.v[e] = (T)0.f;
+    }
+    if (lane_in_row == 0) accb += g;
+    *reinterpret_cast<Vec<T, EPV>*>(dx + row * C + lane_in_row * EPV) = out;
+  }
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) red[threadIdx.x * 9 + e] = acc[e];
+  red[threadIdx.x * 9 + 8] = accb;
+  __syncthreads();
+  if (threadIdx.x < lpr) {
+    for (int e = 0; e < EPV; ++e) {
+      float s = 0.f;
+      for (int q = 0; q < rows_per_it; ++q) s += red[(q * lpr + threadIdx.x) * 9 + e];
+      partial[(size_t)blockIdx.x * (C + 1) + threadIdx.x * EPV + e] = s;
+    }
+    if (threadIdx.x == 0) {
+      float s = 0.f;
+      for (int q = 0; q < rows_per_it; ++q) s += red[(q * lpr) * 9 + 8];
+      partial[(size_t)blockIdx.x * (C + 1) + C] = s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void conv_out_reduce_kernel(const float* __restrict__ partial, int n_wg, int C,
+                                                              float* __restrict__ dw, float* __restrict__ db) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e > C) return;
+  float s = 0.f;
+  for (int g = 0; g < n_wg; ++g) s += partial[(size_t)g * (C + 1) + e];
+  if (e == C) db[0] = s; else dw[e] = s;
+}
+
+static unsigned ew_grid(long long total) { return (unsigned)std::min<long long>(4096, (total + 255) / 256); }
+
+}  // namespace smt
+
+using namespace smt;
+
+extern "C" int smt_gate_mix_fwd(const void* z, void* g, int dtype, int64_t rows, int width, int depth, int ld_z,
+                                int ld_g, smt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int epv = dtype == SMT_BF16 ? 8 : 4;
+  SMT_CHECK_ARG(z && g, "smt_gate_mix_fwd: null pointer");
+  SMT_CHECK_ARG(depth >= 1 && depth <= GM_MAX_DEPTH && width % epv == 0 && ld_z % epv == 0 && ld_g % epv == 0,
+                "smt_gate_mix_fwd: bad geometry");
+  if (rows == 0) return 0;
+  unsigned grid = ew_grid(rows * (width / epv));
+  if (dtype == SMT_BF16)
+    gate_mix_fwd_kernel<__bf16><<<grid, 256, 0, stream>>>((const __bf16*)z, (__bf16*)g, rows, width, depth, ld_z, ld_g);
+  else
+    gate_mix_fwd_kernel<float><<<grid, 256, 0, stream>>>((const float*)z, (float*)g, rows, width, depth, ld_z, ld_g);
+  SMT_CHECK_LAUNCH("gate_mix_fwd");
+  return 0;
+}
+
+extern "C" int smt_gate_mix_bwd(const void* z, const void* dg, void* dz, int dtype, int64_t rows, int width, int depth,
+                                int ld_z, int ld_g, int ld_dz, smt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int epv = dtype == SMT_BF16 ? 8 : 4;
+  SMT_CHECK_ARG(z && dg && dz, "smt_gate_mix_bwd: null pointer");
+  SMT_CHECK_ARG(depth >= 1 && depth <= GM_MAX_DEPTH && width % epv == 0 && ld_z % epv == 0 && ld_g % epv == 0 &&
+                    ld_dz % epv == 0, "smt_gate_mix_bwd: bad geometry");
+  if (rows == 0) return 0;
+  unsigned grid = ew_grid(rows * (width / epv));
+  if (dtype == SMT_BF16)
+    gate_mix_bwd_kernel<__bf16><<<grid, 256, 0, stream>>>((const __bf16*)z, (const __bf16*)dg, (__bf16*)dz, rows, width,
+                                                         depth, ld_z, ld_g, ld_dz);
+  else
+    gate_mix_bwd_kernel<float><<<grid, 256, 0, stream>>>((const float*)z, (const float*)dg, (float*)dz, rows, width,
+                                                        depth, ld_z, ld_g, ld_dz);
+  SMT_CHECK_LAUNCH("gate_mix_bwd");
+  return 0;
+}
+
+extern "C" int smt_conv_in_fwd(const float* x, const float* weight, const float* bias, const int* lens, void* y,
+                               int dtype, int batch, int t_in, int t_out, int c_out, int taps, int stride, int padding,
+                               smt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int epv = dtype == SMT_BF16 ? 8 : 4;
+  SMT_CHECK_ARG(x && weight && bias && y, "smt_conv_in_fwd: null pointer");
+  SMT_CHECK_ARG(c_out % epv == 0 && taps >= 1 && taps <= 8, "smt_conv_in_fwd: bad geometry");
+  if (batch == 0 || t_out == 0) return 0;
+  unsigned grid = ew_grid((long long)batch * t_out * (c_out / epv));
+  if (dtype == SMT_BF16)
+    conv_in_fwd_kernel<__bf16><<<grid, 256, 0, stream>>>(x, weight, bias, lens, (__bf16*)y, batch, t_in, t_out, c_out,
+                                                        taps, stride, padding);
+  else
+    conv_in_fwd_kernel<float><<<grid, 256, 0, stream>>>(x, weight, bias, lens, (float*)y, batch, t_in, t_out, c_out,
+                                                       taps, stride, padding);
+  SMT_CHECK_LAUNCH("conv_in_fwd");
+  return 0;
+}
+
+static int conv_in_wgs(long long rows) { return (int)std::min<long long>(1024, std::max<long long>(1, rows / 512)); }
+
+extern "C" size_t smt_conv_in_wgrad_workspace_bytes(int batch, int t_out, int c_out) {
+  return (size_t)conv_in_wgs((long long)batch * t_out) * c_out * 9 * sizeof(float);
+}
+
+extern "C" int smt_conv_in_wgrad(const float* x, const void* dy, const int* lens, float* dweight, float* dbias,
+                                 int dtype, int batch, int t_in, int t_out, int c_out, int taps, int stride,
+                                 int padding, void* workspace, size_t workspace_bytes, smt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SMT_CHECK_ARG(x && dy && dweight && dbias && workspace, "smt_conv_in_wgrad: null pointer");
+  SMT_CHECK_ARG(c_out <= 256 && 256 % c_out == 0 && taps >= 1 && taps <= 8, "smt_conv_in_wgrad: bad geometry");
+  const long long rows = (long long)batch * t_out;
+  const int n_wg = conv_in_wgs(rows);
+  SMT_CHECK_ARG(workspace_bytes >= smt_conv_in_wgrad_workspace_bytes(batch, t_out, c_out),
+                "smt_conv_in_wgrad: workspace too small");
+  const long long rpw = (rows + n_wg - 1) / n_wg;
+  if (dtype == SMT_BF16)
+    conv_in_wgrad_kernel<__bf16><<<n_wg, 256, 0, stream>>>(x, (const __bf16*)dy, lens, (float*)workspace, batch, t_in,
+                                                          t_out, c_out, taps, stride, padding, rpw);
+  else
+    conv_in_wgrad_kernel<float><<<n_wg, 256, 0, stream>>>(x, (const float*)dy, lens, (float*)workspace, batch, t_in,
+                                                         t_out, c_out, taps, stride, padding, rpw);
+  SMT_CHECK_LAUNCH("conv_in_wgrad");
+  conv_in_wgrad_reduce_kernel<<<(c_out * 9 + 255) / 256, 256, 0, stream>>>((const float*)workspace, n_wg, c_out, taps,
+                                                                           dweight, dbias);
+  SMT_CHECK_LAUNCH("conv_in_wgrad_reduce");
+  return 0;
+}
+
+extern "C" int smt_conv_out_fwd(const void* x, const float* weight, const float* bias, const int* lens, float* y,
+                                int dtype, int batch, int t, int c_in, smt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int epv = dtype == SMT_BF16 ? 8 : 4;
+  SMT_CHECK_ARG(x && weight && bias && y, "smt_conv_out_fwd: null pointer");
+  const int lpr = c_in / epv;
+  SMT_CHECK_ARG(c_in % epv == 0 && lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0, "smt_conv_out_fwd: bad c_in=%d", c_in);
+  if (batch == 0 || t == 0) return 0;
+  unsigned grid = ew_grid((long long)batch * t * lpr);
+  if (dtype == SMT_BF16)
+    conv_out_fwd_kernel<__bf16><<<grid, 256, 0, stream>>>((const __bf16*)x, weight, bias, lens, y, batch, t, c_in);
+  else
+    conv_out_fwd_kernel<float><<<grid, 256, 0, stream>>>((const float*)x, weight, bias, lens, y, batch, t, c_in);
+  SMT_CHECK_LAUNCH("conv_out_fwd");
+  return 0;
+}
+
+extern "C" size_t smt_conv_out_bwd_workspace_bytes(int batch, int t, int c_in) {
+  return (size_t)conv_in_wgs((long long)batch * t) * (c_in + 1) * sizeof(float);
+}
+
+extern "C" int smt_conv_out_bwd(const void* x, const float* weight, const int* lens, const float* dy, void* dx,
+                                float* dweight, float* dbias, int dtype, int batch, int t, int c_in, void* workspace,
+                                size_t workspace_bytes, smt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int epv = dtype == SMT_BF16 ? 8 : 4;
+  SMT_CHECK_ARG(x && weight && dy && dx && dweight && dbias && workspace, "smt_conv_out_bwd: null pointer");
+  const int lpr = c_in / epv;
+  SMT_CHECK_ARG(c_in % epv == 0 && lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0, "smt_conv_out_bwd: bad c_in=%d", c_in);
+  const long long rows = (long long)batch * t;
+  const int n_wg = conv_in_wgs(rows);
+  SMT_CHECK_ARG(workspace_bytes >= smt_conv_out_bwd_workspace_bytes(batch, t, c_in), "smt_conv_out_bwd: workspace too small");
+  const long long rpw = (rows + n_wg - 1) / n_wg;
+  if (dtype == SMT_BF16)
+    conv_out_bwd_kernel<__bf16><<<n_wg, 256, 0, stream>>>((const __bf16*)x, weight, lens, dy, (__bf16*)dx,
+                                                         (float*)workspace, batch, t, c_in, rpw);
+  else
+    conv_out_bwd_kernel<float><<<n_wg, 256, 0, stream>>>((const float*)x, weight, lens, dy, (float*)dx,
+                                                        (float*)workspace, batch, t, c_in, rpw);
+  SMT_CHECK_LAUNCH("conv_out_bwd");
+  conv_out_reduce_kernel<<<(c_in + 1 + 255) / 256, 256, 0, stream>>>((const float*)workspace, n_wg, c_in, dweight, dbias);
+  SMT_CHECK_LAUNCH("conv_out_reduce");
+  return 0;
+}

@@ -28,7 +28,7 @@ void set_error(const char* fmt, ...);
     }                                                                           \
   } while (0)
 
-static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+__host__ __device__ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -1,0 +1,293 @@
+// Windowed STFT on gfx950 as an in-LDS FFT (replaces the reference's DFT-as-conv1d formulation,
+// datasets/transforms.py:86-123, and the multi-resolution spectral loss built on it,
+// models/vqvae/losses.py:39-55).
+//
+// One workgroup (256 threads) owns one frame: the frame is read from HBM with the reflect padding
+// resolved on the fly (coalesced: consecutive lanes read consecutive samples; overlapping frames hit
+// L2), multiplied by the window while it is written to LDS, transformed by a radix-2 Stockham
+// autosort FFT (log2 N passes over two LDS buffers, twiddles from a host-computed fp64->fp32 table),
+// and reduced in place.  Magnitudes are only materialised for the stand-alone STFT / log-mel entry
+// point; the loss kernels keep spectra on chip:
+//   * forward packs the two real signals into ONE complex FFT (z = y + i*yh) and splits the spectra
+//     by Hermitian symmetry, then emits per-frame partial sums of the linear and log terms;
+//   * backward recomputes the spectra, forms dL/dYh on the one-sided spectrum, applies the adjoint
+//     transform (a complex FFT with conjugate twiddles), windows it and overlap-adds into dyh.
+#include "smt_common.h"
+
+namespace smt {
+
+struct cplx { float x, y; };
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+
+// Stockham radix-2; input in `a`, result pointer returned (a or b).  inverse => conjugate twiddles.
+template <int N>
+__device__ __forceinline__ cplx* fft_lds(cplx* a, cplx* b, const cplx* __restrict__ tw, bool inverse) {
+  cplx* in = a; cplx* out = b;
+#pragma unroll 1
+  for (int ns = 1; ns < N; ns <<= 1) {
+    const int tw_stride = N / (2 * ns);
+    for (int j = threadIdx.x; j < N / 2; j += 256) {
+      const int k = j & (ns - 1);
+      cplx w = tw[k * tw_stride];
+      if (inverse) w.y = -w.y;
+      const cplx u = in[j];
+      const cplx v = cmul(in[j + N / 2], w);
+      const int j0 = ((j - k) << 1) + k;
+      out[j0] = {u.x + v.x, u.y + v.y};
+      out[j0 + ns] = {u.x - v.x, u.y - v.y};
+    }
+    __syncthreads();
+    cplx* t = in; in = out; out = t;
+  }
+  return in;
+}
+
+__device__ __forceinline__ int reflect_index(int p, int T) {  // F.pad(mode="reflect") source index
+  if (p < 0) p = -p;
+  if (p >= T) p = 2 * (T - 1) - p;
+  return p;
+}
+
+// ------------------------------------------------------------- magnitudes ------
+// mag[b, k, f] for k in [0, N/2], f in [0, frames)   (reference layout [B, bins, frames])
+template <int N>
+__global__ __launch_bounds__(256) void stft_mag_kernel(const float* __restrict__ x, const float* __restrict__ window,
+                                                       const cplx* __restrict__ tw, float* __restrict__ mag, int T,
+                                                       int hop, int pad, int frames) {
+  __shared__ cplx buf[2][N];
+  const int f = blockIdx.x, b = blockIdx.y;
+  const float* xb = x + (long long)b * T;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float w = window[n];
+    float v = 0.f;
+    if (w != 0.f) v = w * xb[reflect_index(f * hop + n - pad, T)];
+    buf[0][n] = {v, 0.f};
+  }
+  __syncthreads();
+  const cplx* Z = fft_lds<N>(buf[0], buf[1], tw, false);
+  for (int k = threadIdx.x; k <= N / 2; k += 256) {
+    const cplx z = Z[k];
+    mag[((long long)b * (N / 2 + 1) + k) * frames + f] = sqrtf(z.x * z.x + z.y * z.y);
+  }
+}
+
+// ------------------------------------------------------------- loss forward ----
+// part[b, f, 0] = sum_k ((|Y| - |Yh|) m)^2, part[b, f, 1] = sum_k ((log|Y| - log|Yh|) m)^2  (clamp 1e-5)
+template <int N>
+__global__ __launch_bounds__(256) void stft_loss_fwd_kernel(const float* __restrict__ y, const float* __restrict__ yh,
+                                                            const int* __restrict__ lens,
+                                                            const float* __restrict__ window,
+                                                            const cplx* __restrict__ tw, float* __restrict__ part, int T,
+                                                            int hop, int pad, int frames) {
+  __shared__ cplx buf[2][N];
+  __shared__ float red[2][4];
+  const int f = blockIdx.x, b = blockIdx.y;
+  // frame kept iff the sample under its centre tap is unmasked (losses.py:33-37)
+  const int len = lens ? lens[b] : T;
+  const bool keep = (N / 2 - pad + f * hop) < len;
+  float s_lin = 0.f, s_log = 0.f;
+  if (keep) {  // block-uniform
+    const float* yb = y + (long long)b * T;
+    const float* hb = yh + (long long)b * T;
+    for (int n = threadIdx.x; n < N; n += 256) {
+      const float w = window[n];
+      cplx v = {0.f, 0.f};
+      if (w != 0.f) {
+        const int src = reflect_index(f * hop + n - pad, T);
+        v = {w * yb[src], w * hb[src]};
+      }
+      buf[0][n] = v;
+    }
+    __syncthreads();
+    const cplx* Z = fft_lds<N>(buf[0], buf[1], tw, false);
+    for (int k = threadIdx.x; k <= N / 2; k += 256) {
+      const cplx a = Z[k], c = Z[(N - k) & (N - 1)];
+      const float yr = 0.5f * (a.x + c.x), yi = 0.5f * (a.y - c.y);
+      const float hr = 0.5f * (a.y + c.y), hi = -0.5f * (a.x - c.x);
+      const float my = sqrtf(yr * yr + yi * yi), mh = sqrtf(hr * hr + hi * hi);
+      const float d = my - mh;
+      const float dl = __logf(fmaxf(my, 1e-5f)) - __logf(fmaxf(mh, 1e-5f));
+      s_lin = fmaf(d, d, s_lin);
+      s_log = fmaf(dl, dl, s_log);
+    }
+  }
+  s_lin = wave_sum(s_lin);
+  s_log = wave_sum(s_log);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s_lin; red[1][threadIdx.x >> 6] = s_log; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float* o = part + ((long long)b * frames + f) * 2;
+    o[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    o[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+// ------------------------------------------------------------- loss backward ---
+// dyh += adjoint( dL/dYh ),  dL/d|Yh| = -c_lin[b] (|Y|-|Yh|) - c_log[b] (log|Y|-log|Yh|) / |Yh| [|Yh| > 1e-5]
+// coef[b] = {c_lin, c_log} already contains the upstream gradient and the 1/(2 sqrt(S)) factors.
+template <int N>
+__global__ __launch_bounds__(256) void stft_loss_bwd_kernel(const float* __restrict__ y, const float* __restrict__ yh,
+                                                            const int* __restrict__ lens,
+                                                            const float* __restrict__ window,
+                                                            const cplx* __restrict__ tw, const float* __restrict__ coef,
+                                                            float* __restrict__ dyh, int T, int hop, int pad,
+                                                            int frames) {
+  __shared__ cplx buf[2][N];
+  const int f = blockIdx.x, b = blockIdx.y;
+  const int len = lens ? lens[b] : T;
+  if (!((N / 2 - pad + f * hop) < len)) return;  // masked frame: no gradient (block-uniform exit)
+  const float* yb = y + (long long)b * T;
+  const float* hb = yh + (long long)b * T;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float w = window[n];
+    cplx v = {0.f, 0.f};
+    if (w != 0.f) {
+      const int src = reflect_index(f * hop + n - pad, T);
+      v = {w * yb[src], w * hb[src]};
+    }
+    buf[0][n] = v;
+  }
+  __syncthreads();
+  cplx* Z = fft_lds<N>(buf[0], buf[1], tw, false);
+  cplx* G = (Z == buf[0]) ? buf[1] : buf[0];
+  const float c_lin = 2.f * coef[2 * b], c_log = 2.f * coef[2 * b + 1];
+  // one-sided gradient spectrum into G (upper half zero)
+  for (int k = threadIdx.x; k < N; k += 256) {
+    cplx g = {0.f, 0.f};
+    if (k <= N / 2) {
+      const cplx a = Z[k], c = Z[(N - k) & (N - 1)];
+      const float yr = 0.5f * (a.x + c.x), yi = 0.5f * (a.y - c.y);
+      const float hr = 0.5f * (a.y + c.y), hi = -0.5f * (a.x - c.x);
+      const float my = sqrtf(yr * yr + yi * yi), mh = sqrtf(hr * hr + hi * hi);
+      float dmag = -c_lin * (my - mh);
+      if (mh > 1e-5f) dmag -= c_log * (__logf(fmaxf(my, 1e-5f)) - __logf(mh)) / mh;
+      const float inv = mh > 0.f ? dmag / mh : 0.f;
+      g = {inv * hr, inv * hi};
+    }
+    G[k] = g;
+  }
+  __syncthreads();
+  // x_grad[n] = w[n] * Re( sum_k G_k e^{+2 pi i k n / N} )
+  cplx* other = (G == buf[0]) ? buf[1] : buf[0];
+  const cplx* R = fft_lds<N>(G, other, tw, true);
+  float* db = dyh + (long long)b * T;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float w = window[n];
+    if (w != 0.f) atomicAdd(db + reflect_index(f * hop + n - pad, T), w * R[n].x);
+  }
+}
+
+
+// ------------------------------------------------------------- log-mel ---------
+// mel[b, m, f] = log(max(sum_k basis[m][k] |X_k|, 1e-5)); the triangular filters are sparse, so
+// each mel bin only walks its own band [lo[m], hi[m]).  (MelSpectrogram.forward, transforms.py:61-65)
+template <int N>
+__global__ __launch_bounds__(256) void melspec_kernel(const float* __restrict__ x, const float* __restrict__ window,
+                                                      const cplx* __restrict__ tw, const float* __restrict__ basis,
+                                                      const int* __restrict__ band, float* __restrict__ mel, int T,
+                                                      int hop, int pad, int frames, int n_mels) {
+  __shared__ cplx buf[2][N];
+  __shared__ float magn[N / 2 + 1];
+  const int f = blockIdx.x, b = blockIdx.y;
+  const float* xb = x + (long long)b * T;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float w = window[n];
+    float v = 0.f;
+    if (w != 0.f) v = w * xb[reflect_index(f * hop + n - pad, T)];
+    buf[0][n] = {v, 0.f};
+  }
+  __syncthreads();
+  const cplx* Z = fft_lds<N>(buf[0], buf[1], tw, false);
+  for (int k = threadIdx.x; k <= N / 2; k += 256) {
+    const cplx z = Z[k];
+    magn[k] = sqrtf(z.x * z.x + z.y * z.y);
+  }
+  __syncthreads();
+  for (int m = threadIdx.x; m < n_mels; m += 256) {
+    float s = 0.f;
+    const float* row = basis + (long long)m * (N / 2 + 1);
+    for (int k = band[2 * m]; k < band[2 * m + 1]; ++k) s = fmaf(row[k], magn[k], s);
+    mel[((long long)b * n_mels + m) * frames + f] = logf(fmaxf(s, 1e-5f));
+  }
+}
+
+}  // namespace smt
+
+using namespace smt;
+
+#define SMT_FFT_DISPATCH(NFFT, CALL)                                        \
+  switch (NFFT) {                                                           \
+    case 256: { constexpr int N = 256; CALL; } break;                       \
+    case 512: { constexpr int N = 512; CALL; } break;                       \
+    case 1024: { constexpr int N = 1024; CALL; } break;                     \
+    case 2048: { constexpr int N = 2048; CALL; } break;                     \
+    default:                                                                \
+      set_error("stft: n_fft=%d unsupported (256, 512, 1024, 2048)", NFFT); \
+      return 1;                                                             \
+  }
+
+static int stft_frames(int T, int n_fft, int hop) { return (T + 2 * ((n_fft - hop) / 2) - n_fft) / hop + 1; }
+
+extern "C" int smt_stft_num_frames(int t, int n_fft, int hop) { return stft_frames(t, n_fft, hop); }
+
+extern "C" int smt_stft_magnitude(const float* x, const float* window, const float* twiddle, float* mag, int batch,
+                                  int t, int n_fft, int hop, smt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SMT_CHECK_ARG(x && window && twiddle && mag, "smt_stft_magnitude: null pointer");
+  const int pad = (n_fft - hop) / 2;
+  SMT_CHECK_ARG(t > pad, "smt_stft_magnitude: signal shorter than the reflect padding");
+  const int frames = stft_frames(t, n_fft, hop);
+  if (batch == 0 || frames <= 0) return 0;
+  dim3 grid(frames, batch);
+  SMT_FFT_DISPATCH(n_fft, (stft_mag_kernel<N><<<grid, 256, 0, stream>>>(x, window, (const cplx*)twiddle, mag, t, hop,
+                                                                      pad, frames)));
+  SMT_CHECK_LAUNCH("stft_mag");
+  return 0;
+}
+
+extern "C" int smt_stft_loss_fwd(const float* y, const float* yh, const int* lens, const float* window,
+                                 const float* twiddle, float* partial, int batch, int t, int n_fft, int hop,
+                                 smt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SMT_CHECK_ARG(y && yh && window && twiddle && partial, "smt_stft_loss_fwd: null pointer");
+  const int pad = (n_fft - hop) / 2;
+  SMT_CHECK_ARG(t > pad, "smt_stft_loss_fwd: signal shorter than the reflect padding");
+  const int frames = stft_frames(t, n_fft, hop);
+  if (batch == 0 || frames <= 0) return 0;
+  dim3 grid(frames, batch);
+  SMT_FFT_DISPATCH(n_fft, (stft_loss_fwd_kernel<N><<<grid, 256, 0, stream>>>(y, yh, lens, window, (const cplx*)twiddle,
+                                                                           partial, t, hop, pad, frames)));
+  SMT_CHECK_LAUNCH("stft_loss_fwd");
+  return 0;
+}
+
+extern "C" int smt_stft_loss_bwd(const float* y, const float* yh, const int* lens, const float* window,
+                                 const float* twiddle, const float* coef, float* dyh, int batch, int t, int n_fft,
+                                 int hop, smt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SMT_CHECK_ARG(y && yh && window && twiddle && coef && dyh, "smt_stft_loss_bwd: null pointer");
+  const int pad = (n_fft - hop) / 2;
+  const int frames = stft_frames(t, n_fft, hop);
+  if (batch == 0 || frames <= 0) return 0;
+  dim3 grid(frames, batch);
+  SMT_FFT_DISPATCH(n_fft, (stft_loss_bwd_kernel<N><<<grid, 256, 0, stream>>>(y, yh, lens, window, (const cplx*)twiddle,
+                                                                           coef, dyh, t, hop, pad, frames)));
+  SMT_CHECK_LAUNCH("stft_loss_bwd");
+  return 0;
+}
+
+extern "C" int smt_melspec(const float* x, const float* window, const float* twiddle, const float* mel_basis,
+                           const int* band, float* mel, int batch, int t, int n_fft, int hop, int n_mels,
+                           smt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SMT_CHECK_ARG(x && window && twiddle && mel_basis && band && mel, "smt_melspec: null pointer");
+  const int pad = (n_fft - hop) / 2;
+  SMT_CHECK_ARG(t > pad, "smt_melspec: signal shorter than the reflect padding");
+  const int frames = stft_frames(t, n_fft, hop);
+  if (batch == 0 || frames <= 0) return 0;
+  dim3 grid(frames, batch);
+  SMT_FFT_DISPATCH(n_fft, (melspec_kernel<N><<<grid, 256, 0, stream>>>(x, window, (const cplx*)twiddle, mel_basis, band,
+                                                                     mel, t, hop, pad, frames, n_mels)));
+  SMT_CHECK_LAUNCH("melspec");
+  return 0;
+}

@@ -64,14 +64,19 @@ class MelSpectrogram(nn.Module):
         super().__init__()
         self.n_fft, self.hop_length = n_fft, hop_length
         self.stft = STFT(n_fft=n_fft, hop_length=hop_length, win_length=win_length or n_fft, window="hann")
-        self.register_buffer("mel_basis", torch.from_numpy(slaney_mel_filterbank(sample_rate, n_fft, n_mels,
-                                                                                  f_min, f_max)))
+        basis = slaney_mel_filterbank(sample_rate, n_fft, n_mels, f_min, f_max)
+        self.register_buffer("mel_basis", torch.from_numpy(basis))
+        nz = basis > 0
+        lo = np.where(nz.any(1), nz.argmax(1), 0)
+        hi = np.where(nz.any(1), basis.shape[1] - nz[:, ::-1].argmax(1), 0)
+        self.register_buffer("band", torch.from_numpy(np.stack([lo, hi], 1).astype(np.int32)), persistent=False)
 
     def forward(self, audio):
         assert audio.min() >= -1 and audio.max() <= 1
         if audio.dim() == 1:
             audio = audio.unsqueeze(0)
-        return safe_log(torch.matmul(self.mel_basis, self.stft(audio)))
+        stft = self.stft
+        return spectral.log_mel(audio, self.mel_basis, self.band, stft.n_fft, stft.hop_length, stft.win_length)
 
     def mel_len(self, audio_len):
         return audio_len // self.hop_length

@@ -8,6 +8,7 @@ Row masks are prefix masks, carried as per-item lengths: a stride-s conv maps
 L -> ceil(L/s) (``mask[:, :, ::s]``, conv.py:9) and a transposed conv L -> L*s
 (``repeat_interleave``, conv.py:17).
 """
+import torch
 import torch.nn as nn
 
 from smt_amd import convops
@@ -35,12 +36,17 @@ class EncoderConvBlock(nn.Module):
             blocks.append(ConvParams(width, output_emb_width, 3))
         self.blocks = nn.ModuleList(blocks)
         self.n_sites = down_t * 2 * depth
+        self.act_dtype = torch.float32
 
     def forward(self, x, lens, drop_seed=0):
         s = self.stride_t
         for i in range(self.down_t):
             conv, block = self.blocks[2 * i], self.blocks[2 * i + 1]
-            x = convops.conv1d(x, conv.weight, conv.bias, stride=s, padding=s // 2, lens=lens)
+            if conv.c_in == 1:   # raw waveform [B, T] fp32 -> first feature map
+                x = convops.conv_in(x, conv.weight, conv.bias, stride=s, padding=s // 2, lens=lens,
+                                    out_dtype=self.act_dtype)
+            else:
+                x = convops.conv1d(x, conv.weight, conv.bias, stride=s, padding=s // 2, lens=lens)
             lens = (lens + s - 1) // s
             x = block(x, lens, drop_seed)
         if self.down_t > 0:

@@ -24,8 +24,9 @@ class Encoder(nn.Module):
         self.n_sites = base - site_base
 
     def forward(self, x, lens, drop_seed=0):
-        b, t, c = x.shape
-        assert c == self.input_emb_width, f"expected {self.input_emb_width} input channels, got {c}"
+        """x: [B, T] fp32 waveform when input_emb_width == 1, else [B, T, C]."""
+        b, t = x.shape[0], x.shape[1]
+        assert (x.dim() == 2) == (self.input_emb_width == 1)
         for stage, down_t, stride_t in zip(self.level_blocks, self.downs_t, self.strides_t):
             x, lens = stage(x, lens, drop_seed)
             t = t // (stride_t ** down_t)
@@ -57,5 +58,6 @@ class Decoder(nn.Module):
             x, lens = self.level_blocks[level](x, lens, drop_seed)
             t = t * (self.strides_t[level] ** self.downs_t[level])
             assert x.shape == (b, t, self.output_emb_width), f"expected {(b, t, self.output_emb_width)}, got {tuple(x.shape)}"
-        y = convops.conv1d(x, self.out.weight, self.out.bias, lens=lens)
+        assert self.input_emb_width == 1
+        y = convops.conv_out(x.contiguous(), self.out.weight, self.out.bias, lens=lens)   # fp32 [B, T]
         return y, lens

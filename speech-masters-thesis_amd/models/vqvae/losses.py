@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from datasets.transforms import STFT
-from utils.torch_utils import safe_log
+from smt_amd import spectral
 
 
 class MultiResolutionSpectralLoss(nn.Module):
@@ -36,11 +36,7 @@ class MultiResolutionSpectralLoss(nn.Module):
     def forward(self, y, yh, lens):
         loss = 0.0
         for stft in self.stfts:
-            ys, yhs = stft(y), stft(yh)
-            m = self.frame_mask(lens, stft, ys.shape[-1])[:, None, :]
-            loss = loss + ((ys - yhs) * m).pow(2).sum((-1, -2)).sqrt().mean(0)
-            if self.log:
-                loss = loss + ((safe_log(ys) - safe_log(yhs)) * m).pow(2).sum((-1, -2)).sqrt().mean(0)
+            loss = loss + spectral.stft_loss(y, yh, lens, stft.n_fft, stft.hop_length, stft.win_length, self.log)
         return loss / len(self.stfts)
 
 

@@ -54,6 +54,8 @@ class VQVAE(WaveformReconstructionModel):
                                                             linf_topk=loss.linf_topk)
         self.commit, self.multispectral = loss.commit, loss.multispectral
         self.compute_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[m.get("compute_dtype", "fp32")]
+        for stage in encoder.level_blocks:
+            stage.act_dtype = self.compute_dtype
         self._drop_seed = 0
 
     # Checkpoints written by the reference carry the six DFT-basis buffers of the loss
@@ -66,15 +68,13 @@ class VQVAE(WaveformReconstructionModel):
         """x [B, 1, T] float in [-1, 1]; x_lengths [B] -> (loss_dict, vq metrics)."""
         b, c, t = x.shape
         assert c == 1
-        lens = x_lengths.to(torch.int64)
+        lens = x_lengths.to(torch.int32)
         self._drop_seed += 1
-        sig = x.reshape(b, t, 1).to(self.compute_dtype)
-        z, z_lens = self.encoders[0](sig, lens, self._drop_seed)
+        target = x.reshape(b, t)
+        z, z_lens = self.encoders[0](target, lens, self._drop_seed)
         _, xqs, commits, vq_metrics = self.bottleneck([z.float()], [z_lens], **vq_kwargs)
         y, _ = self.decoders[0](xqs[0].to(self.compute_dtype), z_lens, self._drop_seed)
-        assert y.shape == (b, t, 1), f"Expected shape {(b, t, 1)}, got {tuple(y.shape)}."
-        y = y.float().reshape(b, t)
-        target = x.reshape(b, t)
+        assert y.shape == (b, t), f"Expected shape {(b, t)}, got {tuple(y.shape)}."
         loss_recon = self.multi_recon_loss(target, y, lens)
         loss_stft = self.multi_stft_loss(target, y, lens)
         loss_commit = sum(commits)
@@ -86,5 +86,5 @@ class VQVAE(WaveformReconstructionModel):
     def encode_and_quantize(self, x, x_lengths):
         """Encode-only pass of scripts/generate_vq_dataset.py:61-70."""
         b, _, t = x.shape
-        z, z_lens = self.encoders[0](x.reshape(b, t, 1).to(self.compute_dtype), x_lengths.to(torch.int64))
+        z, z_lens = self.encoders[0](x.reshape(b, t), x_lengths.to(torch.int32))
         return self.bottleneck.level_blocks[0].encode(z.float(), z_lens), z_lens

@@ -1,65 +1,391 @@
-"""Channels-last ("NTC", [B, T, C]) building blocks of the encoder / decoder stacks.
+"""Channels-last ("NTC", [B, T, C]) building blocks of the encoder / decoder stacks, on the HIP
+library (include/smt_hip.h, "conv stack").  This is the single seam between the model code
+(models/vqvae/*) and the arithmetic: every function here is a torch.autograd.Function whose forward
+and backward are libsmt_hip.so launches on torch's current stream.
 
-This module is the single seam between the model code (models/vqvae/*) and the
-arithmetic.  ROUND-1 STATUS: the VQ, EMA and loss reductions run in libsmt_hip.so;
-the convolution entry points below are still expressed with PyTorch-ROCm device ops
-(MIOpen) and are being replaced one by one by the hand-written MFMA kernels -- see
-DESIGN.md "kernel status".  They run on the GPU only; nothing here touches the
-oracle or a CPU path.
+    conv1d            implicit-GEMM MFMA conv (any k / dilation / stride), fused input row-mask,
+                      ReLU+dropout prologue, bias, residual
+    conv_transpose1d  the same kernel, one launch per output phase
+    conv_in / conv_out  the C_in = 1 and C_out = 1 ends of the network (HBM-bound kernels)
+    gate_mix          sum_d tanh(t_d) * softmax_d(s_d)
+
+Data gradients are the same GEMM kernel on repacked weights; weight / bias gradients use the
+transposed-fragment kernel (conv_wgrad.hip) with a fixed-order reduction.
 """
+import ctypes
 from dataclasses import dataclass
 from typing import Optional
 
 import torch
-import torch.nn.functional as F
+
+from . import native as N
+from . import profiler
+
+SMT_F32, SMT_BF16 = 0, 1
+_DT = {torch.float32: SMT_F32, torch.bfloat16: SMT_BF16}
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of ``smt_conv_desc`` (include/smt_hip.h)."""
+    _fields_ = [("dtype", ctypes.c_int), ("batch", ctypes.c_int), ("t_in", ctypes.c_int), ("t_out", ctypes.c_int),
+                ("t_y", ctypes.c_int), ("c_in", ctypes.c_int), ("c_out", ctypes.c_int), ("taps", ctypes.c_int),
+                ("stride", ctypes.c_int), ("dilation", ctypes.c_int), ("padding", ctypes.c_int),
+                ("out_stride", ctypes.c_int), ("out_offset", ctypes.c_int), ("act_in", ctypes.c_int),
+                ("act_grad", ctypes.c_int), ("ld_x", ctypes.c_int), ("ld_y", ctypes.c_int), ("ld_res", ctypes.c_int),
+                ("ld_act", ctypes.c_int), ("drop_key", ctypes.c_uint32), ("drop_thresh16", ctypes.c_uint32),
+                ("drop_scale", ctypes.c_float), ("bs_x", ctypes.c_int64), ("bs_y", ctypes.c_int64),
+                ("bs_res", ctypes.c_int64), ("bs_act", ctypes.c_int64), ("x", ctypes.c_void_p), ("w", ctypes.c_void_p),
+                ("bias", ctypes.c_void_p), ("y", ctypes.c_void_p), ("res", ctypes.c_void_p),
+                ("act_grad_src", ctypes.c_void_p), ("lens_in", ctypes.c_void_p), ("lens_out", ctypes.c_void_p)]
 
 
 @dataclass
 class DropSpec:
-    """relu(dropout(x)) prologue of a conv (reference models/vqvae/resnet.py:22-26)."""
+    """relu(dropout(x)) prologue of a conv (reference models/vqvae/resnet.py:22-26) with the
+    counter-based generator of include/smt_hip.h ("dropout")."""
     p: float
     training: bool
     seed: int = 0
     site: int = 0
 
-
-def row_mask(lens: torch.Tensor, t: int, dtype) -> torch.Tensor:
-    """[B, T, 1] prefix mask: 1 where t < lens[b]."""
-    steps = torch.arange(t, device=lens.device)
-    return (steps[None, :] < lens[:, None]).to(dtype).unsqueeze(-1)
-
-
-def _prologue(x, lens, act: Optional[DropSpec]):
-    if lens is not None:
-        x = x * row_mask(lens, x.shape[1], x.dtype)
-    if act is not None:
-        x = torch.relu(F.dropout(x, p=act.p, training=act.training))
-    return x
+    def params(self):
+        """(key, thresh16, scale): eval mode / p == 0 degenerates to a plain ReLU."""
+        if not self.training or self.p <= 0.0:
+            return 0, 0, 1.0
+        return dropout_key(self.seed, self.site), int(round(self.p * 65536.0)), 1.0 / (1.0 - self.p)
 
 
-def conv1d(x, weight, bias, *, stride=1, padding=0, dilation=1, lens=None, act=None, residual=None):
-    """y[b,t,:] = sum_j W_j . pro(x)[b, t*stride + j*dilation - padding, :] + bias (+ residual).
+def _fmix32(h):
+    h &= 0xFFFFFFFF
+    h ^= h >> 16
+    h = (h * 0x85EBCA6B) & 0xFFFFFFFF
+    h ^= h >> 13
+    h = (h * 0xC2B2AE35) & 0xFFFFFFFF
+    h ^= h >> 16
+    return h
+
+
+def dropout_key(seed, site):
+    return _fmix32(seed * 0x9E3779B1 + site * 0x7F4A7C15 + 1)
+
+
+def _geom(t):
+    """(data_ptr, batch stride, row pitch) of a [B, T, C] tensor whose channel axis is dense."""
+    assert t.dim() == 3 and t.stride(2) == 1 and t.is_cuda, "need [B, T, C] with unit channel stride on the GPU"
+    return ctypes.c_void_p(t.data_ptr()), t.stride(0), t.stride(1)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _i32(lens):
+    if lens is None:
+        return None
+    return lens if lens.dtype == torch.int32 else lens.to(torch.int32)
+
+
+def _pack(weight, dtype, n_out, n_in, s_out, s_in, s_tap, tap_map):
+    taps = len(tap_map)
+    dst = torch.empty(taps, n_out, n_in, dtype=dtype, device=weight.device)
+    arr = (ctypes.c_int * taps)(*tap_map)
+    N.check(N.lib().smt_pack_weight(_p(weight), _p(dst), _DT[dtype], n_out, n_in, taps, s_out, s_in, s_tap, arr,
+                                    N.stream_ptr()), "smt_pack_weight")
+    return dst
+
+
+def _launch(desc, name, flops=0.0, nbytes=0.0):
+    dtype = "bf16" if desc.dtype == SMT_BF16 else "f32"
+    with profiler.region(name, nbytes=nbytes, flops=flops, bound="mfma", dtype=dtype):
+        N.check(N.lib().smt_conv1d_ntc(ctypes.byref(desc), N.stream_ptr()), "smt_conv1d_ntc")
+
+
+def _conv_flops(d):
+    return 2.0 * d.batch * d.t_out * d.c_out * d.c_in * d.taps
+
+
+def _conv_bytes(d, esz):
+    return float(d.batch) * (d.t_in * d.c_in + d.t_out * d.c_out) * esz + d.taps * d.c_in * d.c_out * esz
+
+
+def _phases(kernel, stride, padding):
+    """Output-phase decomposition of a transposed convolution: for output index s*m + ph the
+    contributing taps j satisfy (ph + padding - j) % s == 0 and read input row m + (ph+padding-j)/s.
+    Returns per phase (tap list ordered by increasing input offset, effective left padding)."""
+    out = []
+    for ph in range(stride):
+        taps = [(j, (ph + padding - j) // stride) for j in range(kernel) if (ph + padding - j) % stride == 0]
+        taps.sort(key=lambda jt: jt[1])
+        offs = [o for _, o in taps]
+        assert offs == list(range(offs[0], offs[0] + len(offs))), "phase taps must touch consecutive rows"
+        out.append(([j for j, _ in taps], -offs[0]))
+    return out
+
+
+def _base_desc(x, y, lens_in, c_in, c_out, taps, stride, dil, pad, t_out, out_stride=1, out_offset=0):
+    d = ConvDesc()
+    d.dtype = _DT[x.dtype]
+    d.batch, d.t_in, d.t_out, d.t_y = x.shape[0], x.shape[1], t_out, y.shape[1]
+    d.c_in, d.c_out = c_in, c_out
+    d.taps, d.stride, d.dilation, d.padding = taps, stride, dil, pad
+    d.out_stride, d.out_offset = out_stride, out_offset
+    d.x, d.bs_x, d.ld_x = _geom(x)
+    d.y, d.bs_y, d.ld_y = _geom(y)
+    d.lens_in = _p(lens_in)
+    d.drop_scale = 1.0
+    return d
+
+
+def _wgrad(desc, dweight, s_out, s_in, s_tap, tap_map, dbias):
+    lib = N.lib()
+    ws_bytes = lib.smt_conv1d_wgrad_workspace_bytes(ctypes.byref(desc))
+    ws = N.workspace.get(ws_bytes, dweight.device)
+    arr = (ctypes.c_int * len(tap_map))(*tap_map)
+    dtype = "bf16" if desc.dtype == SMT_BF16 else "f32"
+    with profiler.region("conv_wgrad", flops=_conv_flops(desc), bound="mfma", dtype=dtype):
+        N.check(lib.smt_conv1d_wgrad(ctypes.byref(desc), _p(dweight), s_out, s_in, s_tap, arr, _p(dbias), _p(ws),
+                                     ws.numel(), N.stream_ptr()), "smt_conv1d_wgrad")
+
+
+class _Conv1d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, lens, stride, padding, dilation, act):
+        b, t_in, c_in = x.shape
+        c_out, _, k = weight.shape
+        t_out = (t_in + 2 * padding - dilation * (k - 1) - 1) // stride + 1
+        y = torch.empty(b, t_out, c_out, dtype=x.dtype, device=x.device)
+        lens32 = _i32(lens)
+        wp = _pack(weight, x.dtype, c_out, c_in, c_in * k, k, 1, list(range(k)))
+        d = _base_desc(x, y, lens32, c_in, c_out, k, stride, dilation, padding, t_out)
+        d.w, d.bias = _p(wp), _p(bias)
+        key = thresh = 0
+        scale = 1.0
+        if act is not None:
+            key, thresh, scale = act.params()
+            d.act_in, d.drop_key, d.drop_thresh16, d.drop_scale = 1, key, thresh, scale
+        if residual is not None:
+            d.res, d.bs_res, d.ld_res = _geom(residual)
+        _launch(d, "conv_fwd", _conv_flops(d), _conv_bytes(d, x.element_size()))
+        ctx.save_for_backward(x, weight, lens32 if lens32 is not None else torch.empty(0))
+        ctx.cfg = (stride, padding, dilation, act is not None, key, thresh, scale, lens is not None,
+                   residual is not None, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, lens32 = ctx.saved_tensors
+        stride, padding, dilation, has_act, key, thresh, scale, has_lens, has_res, has_bias = ctx.cfg
+        lens32 = lens32 if has_lens else None
+        b, t_in, c_in = x.shape
+        c_out, _, k = weight.shape
+        if dy.stride(2) != 1:
+            dy = dy.contiguous()
+        t_out = dy.shape[1]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(b, t_in, c_in, dtype=x.dtype, device=x.device)
+            if stride == 1:
+                wb = _pack(weight, x.dtype, c_in, c_out, k, c_in * k, 1, [k - 1 - j for j in range(k)])
+                d = _base_desc(dy, dx, None, c_out, c_in, k, 1, dilation, (k - 1) * dilation - padding, t_in)
+                d.w = _p(wb)
+                _finish_dx(d, x, lens32, has_act, key, thresh, scale)
+                _launch(d, "conv_dgrad", _conv_flops(d), _conv_bytes(d, x.element_size()))
+            else:
+                for ph, (taps, pad_eff) in enumerate(_phases(k, stride, padding)):
+                    n_ph = (t_in - ph + stride - 1) // stride
+                    if n_ph <= 0:
+                        continue
+                    wb = _pack(weight, x.dtype, c_in, c_out, k, c_in * k, 1, taps)
+                    d = _base_desc(dy, dx, None, c_out, c_in, len(taps), 1, 1, pad_eff, n_ph, stride, ph)
+                    d.w = _p(wb)
+                    _finish_dx(d, x, lens32, has_act, key, thresh, scale)
+                    _launch(d, "conv_dgrad", _conv_flops(d), _conv_bytes(d, x.element_size()))
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            db = torch.empty(c_out, dtype=torch.float32, device=x.device)
+            d = _base_desc(x, dy, lens32, c_in, c_out, k, stride, dilation, padding, t_out)
+            if has_act:
+                d.act_in, d.drop_key, d.drop_thresh16, d.drop_scale = 1, key, thresh, scale
+            _wgrad(d, dw, c_in * k, k, 1, list(range(k)), db)
+            if not has_bias:
+                db = None
+        return dx, dw, db, (dy if has_res else None), None, None, None, None, None
+
+
+def _finish_dx(d, x, lens32, has_act, key, thresh, scale):
+    """Epilogue of a data gradient: derivative of the forward prologue at the saved input."""
+    if has_act:
+        d.act_grad = 1
+        d.act_grad_src, d.bs_act, d.ld_act = _geom(x)
+        d.drop_key, d.drop_thresh16, d.drop_scale = key, thresh, scale
+    d.lens_out = _p(lens32)
+
+
+def conv1d(x, weight, bias, *, stride=1, padding=0, dilation=1, lens=None, act: Optional[DropSpec] = None,
+           residual=None):
+    """y[b,t,:] = bias + sum_j W_j . pro(x)[b, t*stride + j*dilation - padding, :] (+ residual);
     ``weight`` keeps torch's Conv1d layout [Cout, Cin, k] (checkpoint compatibility)."""
-    x = _prologue(x, lens, act)
-    y = F.conv1d(x.transpose(1, 2), weight.to(x.dtype), bias.to(x.dtype), stride=stride, padding=padding,
-                 dilation=dilation).transpose(1, 2)
-    if residual is not None:
-        y = y + residual
-    return y
+    return _Conv1d.apply(x, weight, bias, residual, lens, stride, padding, dilation, act)
+
+
+class _ConvTranspose1d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, lens, stride, padding):
+        b, t_in, c_in = x.shape
+        _, c_out, k = weight.shape
+        t_y = (t_in - 1) * stride - 2 * padding + k
+        y = torch.empty(b, t_y, c_out, dtype=x.dtype, device=x.device)
+        lens32 = _i32(lens)
+        for ph, (taps, pad_eff) in enumerate(_phases(k, stride, padding)):
+            n_ph = (t_y - ph + stride - 1) // stride
+            wp = _pack(weight, x.dtype, c_out, c_in, k, c_out * k, 1, taps)
+            d = _base_desc(x, y, lens32, c_in, c_out, len(taps), 1, 1, pad_eff, n_ph, stride, ph)
+            d.w, d.bias = _p(wp), _p(bias)
+            _launch(d, "conv_fwd", _conv_flops(d), _conv_bytes(d, x.element_size()))
+        ctx.save_for_backward(x, weight, lens32 if lens32 is not None else torch.empty(0))
+        ctx.cfg = (stride, padding, lens is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, lens32 = ctx.saved_tensors
+        stride, padding, has_lens = ctx.cfg
+        lens32 = lens32 if has_lens else None
+        b, t_in, c_in = x.shape
+        _, c_out, k = weight.shape
+        if dy.stride(2) != 1:
+            dy = dy.contiguous()
+        t_y = dy.shape[1]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # dx[m, ci] = sum_j sum_co dy[s*m + j - p, co] W[ci, co, j]: a strided convolution over dy
+            dx = torch.empty(b, t_in, c_in, dtype=x.dtype, device=x.device)
+            wb = _pack(weight, x.dtype, c_in, c_out, c_out * k, k, 1, list(range(k)))
+            d = _base_desc(dy, dx, None, c_out, c_in, k, stride, 1, padding, t_in)
+            d.w = _p(wb)
+            d.lens_out = _p(lens32)
+            _launch(d, "conv_dgrad", _conv_flops(d), _conv_bytes(d, x.element_size()))
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            db = torch.zeros(c_out, dtype=torch.float32, device=x.device)
+            for ph, (taps, pad_eff) in enumerate(_phases(k, stride, padding)):
+                n_ph = (t_y - ph + stride - 1) // stride
+                d = _base_desc(x, dy, lens32, c_in, c_out, len(taps), 1, 1, pad_eff, n_ph, stride, ph)
+                db_ph = torch.empty(c_out, dtype=torch.float32, device=x.device)
+                _wgrad(d, dw, k, c_out * k, 1, taps, db_ph)
+                db += db_ph
+        return dx, dw, db, None, None, None
 
 
 def conv_transpose1d(x, weight, bias, *, stride, padding, lens=None):
-    """ConvTranspose1d with torch's [Cin, Cout, k] weight layout."""
-    x = _prologue(x, lens, None)
-    return F.conv_transpose1d(x.transpose(1, 2), weight.to(x.dtype), bias.to(x.dtype), stride=stride,
-                              padding=padding).transpose(1, 2)
+    """ConvTranspose1d with torch's [Cin, Cout, k] weight layout (one launch per output phase)."""
+    return _ConvTranspose1d.apply(x, weight, bias, lens, stride, padding)
+
+
+class _GateMix(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, depth):
+        b, t, c = z.shape
+        w = c // (2 * depth)
+        g = torch.empty(b, t, w, dtype=z.dtype, device=z.device)
+        assert z.is_contiguous()
+        with profiler.region("gate_mix_fwd", nbytes=z.numel() * z.element_size() * 1.125, bound="hbm"):
+            N.check(N.lib().smt_gate_mix_fwd(_p(z), _p(g), _DT[z.dtype], b * t, w, depth, c, w, N.stream_ptr()),
+                    "smt_gate_mix_fwd")
+        ctx.save_for_backward(z)
+        ctx.depth = depth
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        z, = ctx.saved_tensors
+        b, t, c = z.shape
+        w = c // (2 * ctx.depth)
+        dg = dg.contiguous()
+        dz = torch.empty_like(z)
+        with profiler.region("gate_mix_bwd", nbytes=z.numel() * z.element_size() * 2.125, bound="hbm"):
+            N.check(N.lib().smt_gate_mix_bwd(_p(z), _p(dg), _p(dz), _DT[z.dtype], b * t, w, ctx.depth, c, w, c,
+                                             N.stream_ptr()), "smt_gate_mix_bwd")
+        return dz, None
 
 
 def gate_mix(z, depth: int):
-    """sum_d tanh(t_d) * softmax_d(s_d) over the ``depth`` branches laid side by side in the channel
-    dimension: z = [.., d*(2w) + (0..w-1)] = t_d, [.., d*(2w) + (w..2w-1)] = s_d
-    (reference models/vqvae/resnet.py:229-237)."""
-    b, t, c = z.shape
-    w = c // (2 * depth)
-    z = z.view(b, t, depth, 2, w)
-    return (torch.tanh(z[:, :, :, 0]) * torch.softmax(z[:, :, :, 1].float(), dim=2).to(z.dtype)).sum(dim=2)
+    """sum_d tanh(t_d) * softmax_d(s_d); z = [.., d*2w + (0..w-1)] = t_d, [.., d*2w + (w..2w-1)] = s_d."""
+    return _GateMix.apply(z, depth)
+
+
+class _ConvIn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, lens, stride, padding, out_dtype):
+        b, t_in = x.shape
+        c_out, _, k = weight.shape
+        t_out = (t_in + 2 * padding - k) // stride + 1
+        y = torch.empty(b, t_out, c_out, dtype=out_dtype, device=x.device)
+        lens32 = _i32(lens)
+        with profiler.region("conv_in_fwd", nbytes=x.numel() * 4 + y.numel() * y.element_size(), bound="hbm"):
+            N.check(N.lib().smt_conv_in_fwd(_p(x), _p(weight), _p(bias), _p(lens32), _p(y), _DT[out_dtype], b, t_in,
+                                            t_out, c_out, k, stride, padding, N.stream_ptr()), "smt_conv_in_fwd")
+        ctx.save_for_backward(x, weight, lens32 if lens32 is not None else torch.empty(0))
+        ctx.cfg = (stride, padding, lens is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, lens32 = ctx.saved_tensors
+        stride, padding, has_lens = ctx.cfg
+        lens32 = lens32 if has_lens else None
+        b, t_in = x.shape
+        c_out, _, k = weight.shape
+        dy = dy.contiguous()
+        dw = torch.empty_like(weight)
+        db = torch.empty(c_out, dtype=torch.float32, device=x.device)
+        lib = N.lib()
+        ws_bytes = lib.smt_conv_in_wgrad_workspace_bytes(b, dy.shape[1], c_out)
+        ws = N.workspace.get(ws_bytes, x.device)
+        with profiler.region("conv_in_wgrad", nbytes=x.numel() * 4 + dy.numel() * dy.element_size(), bound="hbm"):
+            N.check(lib.smt_conv_in_wgrad(_p(x), _p(dy), _p(lens32), _p(dw), _p(db), _DT[dy.dtype], b, t_in,
+                                          dy.shape[1], c_out, k, stride, padding, _p(ws), ws.numel(), N.stream_ptr()),
+                    "smt_conv_in_wgrad")
+        return None, dw, db, None, None, None, None
+
+
+def conv_in(x, weight, bias, *, stride, padding, lens=None, out_dtype=torch.float32):
+    """First encoder conv: x fp32 [B, T] (one channel) -> [B, T_out, C]."""
+    return _ConvIn.apply(x, weight, bias, lens, stride, padding, out_dtype)
+
+
+class _ConvOut(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, lens):
+        b, t, c = x.shape
+        assert x.is_contiguous()
+        y = torch.empty(b, t, dtype=torch.float32, device=x.device)
+        lens32 = _i32(lens)
+        with profiler.region("conv_out_fwd", nbytes=x.numel() * x.element_size() + y.numel() * 4, bound="hbm"):
+            N.check(N.lib().smt_conv_out_fwd(_p(x), _p(weight), _p(bias), _p(lens32), _p(y), _DT[x.dtype], b, t, c,
+                                             N.stream_ptr()), "smt_conv_out_fwd")
+        ctx.save_for_backward(x, weight, lens32 if lens32 is not None else torch.empty(0))
+        ctx.has_lens = lens is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, lens32 = ctx.saved_tensors
+        lens32 = lens32 if ctx.has_lens else None
+        b, t, c = x.shape
+        dy = dy.contiguous().float()
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(weight)
+        db = torch.empty(1, dtype=torch.float32, device=x.device)
+        lib = N.lib()
+        ws_bytes = lib.smt_conv_out_bwd_workspace_bytes(b, t, c)
+        ws = N.workspace.get(ws_bytes, x.device)
+        with profiler.region("conv_out_bwd", nbytes=2 * x.numel() * x.element_size() + dy.numel() * 4, bound="hbm"):
+            N.check(lib.smt_conv_out_bwd(_p(x), _p(weight), _p(lens32), _p(dy), _p(dx), _p(dw), _p(db), _DT[x.dtype], b,
+                                         t, c, _p(ws), ws.numel(), N.stream_ptr()), "smt_conv_out_bwd")
+        return dx, dw, db, None
+
+
+def conv_out(x, weight, bias, *, lens=None):
+    """Final decoder projection to one channel on masked rows: [B, T, C] -> fp32 [B, T]."""
+    return _ConvOut.apply(x, weight, bias, lens)

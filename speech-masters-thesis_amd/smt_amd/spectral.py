@@ -1,46 +1,106 @@
-"""Spectral front end and loss reductions.
+"""Spectral front end and spectral loss on the HIP library (include/smt_hip.h, "spectral"):
+in-LDS FFT instead of the reference's DFT-as-conv1d (datasets/transforms.py:86-123).
 
-ROUND-1 STATUS: device ops expressed with PyTorch-ROCm (strided conv1d against the
-windowed DFT basis, exactly the reference formulation, datasets/transforms.py:86-123);
-the LDS radix-FFT kernel replaces ``stft_magnitude`` next (DESIGN.md "kernel status").
+Window and twiddle tables are computed once per (n_fft, win_length) in float64 and cached on
+the device; the kernels never evaluate sin/cos.
 """
-import functools
 import math
 
 import torch
-import torch.nn.functional as F
+
+from . import native as N
+from . import profiler
+
+_tables = {}
 
 
-@functools.lru_cache(maxsize=16)
-def _basis_cpu(n_fft, win_length):
-    bins = n_fft // 2 + 1
-    k = torch.arange(bins, dtype=torch.float64)[:, None]
-    n = torch.arange(n_fft, dtype=torch.float64)[None, :]
-    phase = 2.0 * math.pi * torch.remainder(k * n, n_fft) / n_fft
-    basis = torch.cat([torch.cos(phase), -torch.sin(phase)], dim=0).to(torch.float32)
-    m = torch.arange(win_length, dtype=torch.float64)
-    hann = (0.5 - 0.5 * torch.cos(2.0 * math.pi * m / win_length)).to(torch.float32)
-    window = torch.zeros(n_fft)
-    lpad = (n_fft - win_length) // 2
-    window[lpad:lpad + win_length] = hann
-    return (basis * window)[:, None, :].contiguous()
-
-
-_basis_dev = {}
-
-
-def windowed_dft_basis(n_fft, win_length, device):
+def _get_tables(n_fft, win_length, device):
     key = (n_fft, win_length, str(device))
-    if key not in _basis_dev:
-        _basis_dev[key] = _basis_cpu(n_fft, win_length).to(device)
-    return _basis_dev[key]
+    if key not in _tables:
+        m = torch.arange(win_length, dtype=torch.float64)
+        hann = 0.5 - 0.5 * torch.cos(2.0 * math.pi * m / win_length)       # periodic Hann (fftbins=True)
+        window = torch.zeros(n_fft, dtype=torch.float64)
+        lpad = (n_fft - win_length) // 2                                      # librosa.util.pad_center
+        window[lpad:lpad + win_length] = hann
+        k = torch.arange(n_fft // 2, dtype=torch.float64)
+        ang = -2.0 * math.pi * k / n_fft
+        tw = torch.stack([torch.cos(ang), torch.sin(ang)], dim=-1)
+        _tables[key] = (window.to(torch.float32).to(device), tw.to(torch.float32).contiguous().to(device))
+    return _tables[key]
 
 
+def num_frames(t, n_fft, hop):
+    return (t + 2 * ((n_fft - hop) // 2) - n_fft) // hop + 1
+
+
+@torch.no_grad()
 def stft_magnitude(x, n_fft, hop, win_length):
-    """x [B, T] -> [B, n_fft/2+1, frames]."""
+    """x [B, T] fp32 -> |STFT| [B, n_fft/2+1, frames] (STFT.forward, transforms.py:108-123)."""
+    x = x.contiguous().float()
     b, t = x.shape
-    pad = (n_fft - hop) // 2
-    xp = F.pad(x.reshape(b, 1, 1, t), (pad, pad, 0, 0), mode="reflect").reshape(b, 1, t + 2 * pad)
-    ft = F.conv1d(xp, windowed_dft_basis(n_fft, win_length, x.device), stride=hop)
-    bins = n_fft // 2 + 1
-    return torch.sqrt(ft[:, :bins] ** 2 + ft[:, bins:] ** 2)
+    window, tw = _get_tables(n_fft, win_length, x.device)
+    frames = num_frames(t, n_fft, hop)
+    mag = torch.empty(b, n_fft // 2 + 1, frames, dtype=torch.float32, device=x.device)
+    with profiler.region("stft_mag", nbytes=x.numel() * 4 + mag.numel() * 4, bound="hbm"):
+        N.check(N.lib().smt_stft_magnitude(N.ptr(x), N.ptr(window), N.ptr(tw), N.ptr(mag), b, t, n_fft, hop,
+                                           N.stream_ptr()), "smt_stft_magnitude")
+    return mag
+
+
+@torch.no_grad()
+def log_mel(x, mel_basis, band, n_fft, hop, win_length):
+    """x [B, T] -> log-mel [B, n_mels, frames] in one kernel (5.25 B/sample algorithmic)."""
+    x = x.contiguous().float()
+    b, t = x.shape
+    window, tw = _get_tables(n_fft, win_length, x.device)
+    frames = num_frames(t, n_fft, hop)
+    n_mels = mel_basis.shape[0]
+    mel = torch.empty(b, n_mels, frames, dtype=torch.float32, device=x.device)
+    with profiler.region("melspec", nbytes=x.numel() * 4 + mel.numel() * 4, bound="hbm"):
+        N.check(N.lib().smt_melspec(N.ptr(x), N.ptr(window), N.ptr(tw), N.ptr(mel_basis), N.ptr(band), N.ptr(mel), b, t,
+                                    n_fft, hop, n_mels, N.stream_ptr()), "smt_melspec")
+    return mel
+
+
+class _StftLoss(torch.autograd.Function):
+    """mean_b sqrt(sum ((|Y|-|Yh|) m)^2) [+ the same on clamped log magnitudes] for ONE resolution."""
+
+    @staticmethod
+    def forward(ctx, y, yh, lens, n_fft, hop, win_length, use_log):
+        y, yh = y.contiguous().float(), yh.contiguous().float()
+        b, t = y.shape
+        window, tw = _get_tables(n_fft, win_length, y.device)
+        frames = num_frames(t, n_fft, hop)
+        part = torch.empty(b, frames, 2, dtype=torch.float32, device=y.device)
+        lens32 = None if lens is None else lens.to(torch.int32)
+        with profiler.region("stft_loss_fwd", nbytes=2 * y.numel() * 4, bound="hbm"):
+            N.check(N.lib().smt_stft_loss_fwd(N.ptr(y), N.ptr(yh), N.ptr(lens32), N.ptr(window), N.ptr(tw),
+                                              N.ptr(part), b, t, n_fft, hop, N.stream_ptr()), "smt_stft_loss_fwd")
+        sums = part.sum(dim=1)                       # [B, 2]; fixed-order reduction of tiny tensors
+        root = sums.sqrt()
+        loss = root[:, 0].mean() + (root[:, 1].mean() if use_log else 0.0)
+        ctx.save_for_backward(y, yh, lens32 if lens32 is not None else torch.empty(0), root)
+        ctx.cfg = (n_fft, hop, win_length, use_log, lens is not None)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        y, yh, lens32, root = ctx.saved_tensors
+        n_fft, hop, win_length, use_log, has_lens = ctx.cfg
+        lens32 = lens32 if has_lens else None
+        b, t = y.shape
+        window, tw = _get_tables(n_fft, win_length, y.device)
+        coef = (g / (2.0 * b)) / root.clamp(min=1e-30)          # d sqrt(S)/dS = 1/(2 sqrt(S)), mean over B
+        if not use_log:
+            coef = coef * torch.tensor([1.0, 0.0], device=coef.device)
+        coef = coef.contiguous().float()
+        dyh = torch.zeros_like(yh)
+        with profiler.region("stft_loss_bwd", nbytes=3 * y.numel() * 4, bound="hbm"):
+            N.check(N.lib().smt_stft_loss_bwd(N.ptr(y), N.ptr(yh), N.ptr(lens32), N.ptr(window), N.ptr(tw),
+                                              N.ptr(coef), N.ptr(dyh), b, t, n_fft, hop, N.stream_ptr()),
+                    "smt_stft_loss_bwd")
+        return None, dyh, None, None, None, None, None
+
+
+def stft_loss(y, yh, lens, n_fft, hop, win_length, use_log):
+    return _StftLoss.apply(y, yh, lens, n_fft, hop, win_length, use_log)

@@ -6,6 +6,7 @@ Host-side counterpart of BottleneckBlock.quantize/dequantize/update_k
 import torch
 
 from . import native as N
+from . import profiler
 
 
 def vq_forward_raw(x, codebook, row_mask=None, want_xd=True):
@@ -21,8 +22,12 @@ def vq_forward_raw(x, codebook, row_mask=None, want_xd=True):
     sums = torch.empty(4, dtype=torch.float32, device=x.device)
     ws_bytes = lib.smt_vq_forward_workspace_bytes(n, k, d)
     ws = N.workspace.get(ws_bytes, x.device)
-    N.check(lib.smt_vq_forward(N.ptr(x), N.ptr(codebook), N.ptr(row_mask), n, k, d, N.ptr(idx), N.ptr(min_dist),
-                               N.ptr(x_d), N.ptr(sums), N.ptr(ws), ws.numel(), N.stream_ptr()), "smt_vq_forward")
+    # algorithmic bytes: 4D read + 8 idx + 4 min_dist (+ 4D x_d) per row, + codebook once
+    nbytes = n * (4 * d + 12 + (4 * d if want_xd else 0)) + 4 * k * d
+    with profiler.region("vq_forward", nbytes=nbytes, flops=2.0 * n * k * d, bound="hbm"):
+        N.check(lib.smt_vq_forward(N.ptr(x), N.ptr(codebook), N.ptr(row_mask), n, k, d, N.ptr(idx),
+                                   N.ptr(min_dist), N.ptr(x_d), N.ptr(sums), N.ptr(ws), ws.numel(),
+                                   N.stream_ptr()), "smt_vq_forward")
     return idx, min_dist, x_d, sums
 
 
@@ -71,8 +76,9 @@ def ema_stats_numel(k_bins, dim):
 def ema_accumulate(x, idx, row_mask, k_bins, stats):
     n, d = x.shape
     lib = N.lib()
-    N.check(lib.smt_vq_ema_accumulate(N.ptr(x), N.ptr(idx), N.ptr(row_mask), n, k_bins, d, N.ptr(stats),
-                                      N.stream_ptr()), "smt_vq_ema_accumulate")
+    with profiler.region("vq_ema_accumulate", nbytes=n * (4 * d + 8) + 8 * k_bins * (d + 1), bound="hbm"):
+        N.check(lib.smt_vq_ema_accumulate(N.ptr(x), N.ptr(idx), N.ptr(row_mask), n, k_bins, d, N.ptr(stats),
+                                          N.stream_ptr()), "smt_vq_ema_accumulate")
 
 
 @torch.no_grad()

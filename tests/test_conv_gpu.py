@@ -1,0 +1,210 @@
+"""Conv-stack kernels (libsmt_hip.so via smt_amd.convops) against a plain PyTorch fp32 reference of
+the same op on the GPU.  fp32 path: exact-fp32 MFMA fma chains -> tight tolerance; bf16 path: bf16
+operands / fp32 accumulate -> tolerance relative to the tensor's max magnitude."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import vqvae_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def tol(dtype):
+    return dict(f=2e-5, g=2e-4) if dtype == torch.float32 else dict(f=1.5e-2, g=3e-2)
+
+
+def close(a, b, rel):
+    a, b = a.float(), b.float()
+    return (a - b).abs().max().item() <= rel * b.abs().max().item() + 1e-6
+
+
+def ref_mask(lens, t):
+    return (torch.arange(t, device=lens.device)[None, :] < lens[:, None]).float().unsqueeze(-1)
+
+
+GEOMS = [  # cin, cout, k, dil, stride, pad
+    (64, 128, 1, 1, 1, 0), (128, 128, 3, 1, 1, 1), (128, 128, 5, 3, 1, 6), (128, 128, 7, 9, 1, 27),
+    (128, 128, 9, 27, 1, 108), (64, 64, 4, 1, 2, 1), (128, 64, 4, 1, 2, 1), (64, 128, 3, 1, 1, 1),
+    (16, 32, 3, 1, 1, 1), (32, 32, 9, 27, 1, 108), (32, 16, 4, 1, 2, 1), (512, 64, 1, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("geom", GEOMS)
+def test_conv1d_forward_backward(geom, dtype):
+    from smt_amd import convops
+    cin, cout, k, dil, stride, pad = geom
+    g = torch.Generator(device="cuda").manual_seed(hash(geom) % 1000)
+    b, t = 3, 2 * 173 if stride == 2 else 333
+    x = torch.randn(b, t, cin, device="cuda", generator=g)
+    w = torch.randn(cout, cin, k, device="cuda", generator=g) / (cin * k) ** 0.5
+    bias = torch.randn(cout, device="cuda", generator=g)
+    lens = torch.tensor([t, t - 37, 5], device="cuda", dtype=torch.int32)
+    t_out = (t + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    res = torch.randn(b, t_out, cout, device="cuda", generator=g)
+    xq, resq = x.to(dtype), res.to(dtype)
+
+    xa = xq.clone().requires_grad_(True); wa = w.clone().requires_grad_(True); ba = bias.clone().requires_grad_(True)
+    ra = resq.clone().requires_grad_(True)
+    y = convops.conv1d(xa, wa, ba, stride=stride, padding=pad, dilation=dil, lens=lens, residual=ra)
+    dy = torch.randn(b, t_out, cout, device="cuda", generator=g).to(dtype)
+    y.backward(dy)
+
+    xr = xq.float().clone().requires_grad_(True); wr = w.to(dtype).float().clone().requires_grad_(True)
+    br = bias.clone().requires_grad_(True); rr = resq.float().clone().requires_grad_(True)
+    yr = F.conv1d((xr * ref_mask(lens, t)).transpose(1, 2), wr, br, stride=stride, padding=pad, dilation=dil)
+    yr = yr.transpose(1, 2) + rr
+    yr.backward(dy.float())
+    tl = tol(dtype)
+    assert y.shape == yr.shape
+    assert close(y, yr, tl["f"]), "forward"
+    assert close(xa.grad, xr.grad, tl["g"]), "dx"
+    assert close(wa.grad, wr.grad, tl["g"]), "dw"
+    assert close(ba.grad, br.grad, tl["g"]), "db"
+    assert torch.equal(ra.grad, dy)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("p,training", [(0.1, True), (0.1, False), (0.0, True)])
+def test_relu_dropout_prologue_matches_counter_spec(dtype, p, training):
+    """relu(dropout(x)) fused into the conv: the mask is the counter-based generator restated by the
+    oracle (bit-exact), so forward AND both gradients are checkable in train mode."""
+    from smt_amd import convops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    b, t, c, k, dil, pad = 2, 301, 128, 5, 3, 6
+    x = torch.randn(b, t, c, device="cuda", generator=g).to(dtype)
+    w = torch.randn(c, c, k, device="cuda", generator=g) / (c * k) ** 0.5
+    bias = torch.zeros(c, device="cuda")
+    seed, site = 17, 9
+    act = convops.DropSpec(p, training, seed, site)
+    xa = x.clone().requires_grad_(True); wa = w.clone().requires_grad_(True)
+    y = convops.conv1d(xa, wa, bias, padding=pad, dilation=dil, act=act)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    if training and p > 0:
+        keep = torch.from_numpy(orc.dropout_keep_ntc(seed, site, b, t, c, p)).cuda().float() / (1.0 - p)
+        assert abs(keep.gt(0).float().mean().item() - (1 - p)) < 0.01
+    else:
+        keep = torch.ones(b, t, c, device="cuda")
+    xr = x.float().clone().requires_grad_(True); wr = w.to(dtype).float().clone().requires_grad_(True)
+    u = torch.relu(xr * keep)
+    if dtype == torch.bfloat16:
+        u = u + (u.to(dtype).float() - u).detach()     # the kernel rounds the activated operand to bf16
+    yr = F.conv1d(u.transpose(1, 2), wr, bias, padding=pad, dilation=dil).transpose(1, 2)
+    yr.backward(dy.float())
+    tl = tol(dtype)
+    assert close(y, yr, tl["f"]) and close(xa.grad, xr.grad, tl["g"]) and close(wa.grad, wr.grad, tl["g"])
+    # masked positions have exactly zero gradient
+    assert torch.equal(xa.grad.float() == 0, ~((x.float() > 0) & (keep > 0)) | (xr.grad == 0))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout", [(64, 64), (64, 128), (16, 32)])
+def test_conv_transpose1d(cin, cout, dtype):
+    from smt_amd import convops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    b, t, k, s, pad = 3, 211, 4, 2, 1
+    x = torch.randn(b, t, cin, device="cuda", generator=g).to(dtype)
+    w = torch.randn(cin, cout, k, device="cuda", generator=g) / (cin * 2) ** 0.5
+    bias = torch.randn(cout, device="cuda", generator=g)
+    lens = torch.tensor([t, 100, 0], device="cuda", dtype=torch.int32)
+    xa = x.clone().requires_grad_(True); wa = w.clone().requires_grad_(True); ba = bias.clone().requires_grad_(True)
+    y = convops.conv_transpose1d(xa, wa, ba, stride=s, padding=pad, lens=lens)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    xr = x.float().clone().requires_grad_(True); wr = w.to(dtype).float().clone().requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    yr = F.conv_transpose1d((xr * ref_mask(lens, t)).transpose(1, 2), wr, br, stride=s, padding=pad).transpose(1, 2)
+    yr.backward(dy.float())
+    tl = tol(dtype)
+    assert y.shape == yr.shape == (b, 2 * t, cout)
+    assert close(y, yr, tl["f"]) and close(xa.grad, xr.grad, tl["g"])
+    assert close(wa.grad, wr.grad, tl["g"]) and close(ba.grad, br.grad, tl["g"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gate_mix(dtype):
+    from smt_amd import convops
+    g = torch.Generator(device="cuda").manual_seed(4)
+    b, t, w, depth = 2, 157, 64, 4
+    z = (2 * torch.randn(b, t, depth * 2 * w, device="cuda", generator=g)).to(dtype)
+    za = z.clone().requires_grad_(True)
+    out = convops.gate_mix(za, depth)
+    dg = torch.randn_like(out)
+    out.backward(dg)
+    zr = z.float().clone().requires_grad_(True)
+    zz = zr.view(b, t, depth, 2, w)
+    ref = (torch.tanh(zz[:, :, :, 0]) * torch.softmax(zz[:, :, :, 1], dim=2)).sum(2)
+    ref.backward(dg.float())
+    tl = tol(dtype)
+    assert close(out, ref, max(tl["f"], 1e-5)) and close(za.grad, zr.grad, max(tl["g"], 1e-4))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_in_and_conv_out(dtype):
+    from smt_amd import convops
+    g = torch.Generator(device="cuda").manual_seed(6)
+    b, t, c = 3, 1000, 64
+    x = torch.rand(b, t, device="cuda", generator=g) * 2 - 1
+    w = torch.randn(c, 1, 4, device="cuda", generator=g) * 0.5
+    bias = torch.randn(c, device="cuda", generator=g)
+    lens = torch.tensor([t, 640, 128], device="cuda", dtype=torch.int32)
+    wa = w.clone().requires_grad_(True); ba = bias.clone().requires_grad_(True)
+    y = convops.conv_in(x, wa, ba, stride=2, padding=1, lens=lens, out_dtype=dtype)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    wr = w.clone().requires_grad_(True); br = bias.clone().requires_grad_(True)
+    yr = F.conv1d((x.unsqueeze(-1) * ref_mask(lens, t)).transpose(1, 2), wr, br, stride=2, padding=1).transpose(1, 2)
+    yr.backward(dy.float())
+    tl = tol(dtype)
+    assert close(y, yr, max(tl["f"], 1e-6) if dtype == torch.float32 else 8e-3)
+    assert close(wa.grad, wr.grad, 1e-4) and close(ba.grad, br.grad, 1e-4)
+
+    c2 = 128
+    h = torch.randn(b, t, c2, device="cuda", generator=g).to(dtype)
+    wo = torch.randn(1, c2, 1, device="cuda", generator=g) * 0.1
+    bo = torch.randn(1, device="cuda", generator=g)
+    ha = h.clone().requires_grad_(True); woa = wo.clone().requires_grad_(True); boa = bo.clone().requires_grad_(True)
+    o = convops.conv_out(ha, woa, boa, lens=lens)
+    do = torch.randn_like(o)
+    o.backward(do)
+    hr = h.float().clone().requires_grad_(True); wor = wo.clone().requires_grad_(True); bor = bo.clone().requires_grad_(True)
+    oref = F.conv1d((hr * ref_mask(lens, t)).transpose(1, 2), wor, bor)[:, 0]
+    oref.backward(do)
+    assert o.dtype == torch.float32 and close(o, oref, 1e-5)
+    assert close(ha.grad, hr.grad, tl["f"]) and close(woa.grad, wor.grad, 1e-4) and close(boa.grad, bor.grad, 1e-4)
+
+
+def test_gated_hifi_block_forward_backward_vs_oracle(golden):
+    """One GatedHiFiBlock (reference fixture, eval mode) through the product modules: forward against
+    the reference output, parameter + input gradients against the oracle's autograd (fp32)."""
+    from models.vqvae.resnet import GatedHiFiBlock
+    g = golden("gated_hifi")
+    blk = GatedHiFiBlock(16, 4, dilation_growth_rate=3, kernel_size_growth_rate=2, zero_out=True).cuda()
+    sd = {k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("p.")}
+    blk.load_state_dict(sd)
+    blk.eval()
+    x_nct = torch.from_numpy(g["x"])
+    lens = torch.from_numpy(g["lens"])
+    xa = x_nct.permute(0, 2, 1).contiguous().cuda().requires_grad_(True)
+    y = blk(xa, lens.cuda().to(torch.int32))
+    assert torch.allclose(y.detach().cpu().permute(0, 2, 1), torch.from_numpy(g["y"]), atol=2e-5)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(0))
+    y.backward(dy.cuda())
+    # oracle autograd on CPU
+    p = {"b." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x_nct.clone().requires_grad_(True)
+    mask = orc.sequence_mask(lens, x_nct.shape[-1]).unsqueeze(1).float()
+    yr = orc.gated_hifi_block(xr, mask, p, "b", orc.VQVAEConfig(width=16, multipliers=(1, 1, 1)), orc.no_dropout)
+    yr.backward(dy.permute(0, 2, 1))
+    # A pre-activation that is ~0 can land on the other side of the ReLU on the GPU (different fp32
+    # summation order); one such flip changes a handful of gradient entries by O(1e-2) of the max.
+    # So the metric is the relative L2 error of each tensor.
+    def check(a, b, name):
+        a, b = a.float(), b.float()
+        assert (a - b).norm() <= 2e-2 * b.norm() + 1e-7, name
+    check(xa.grad.cpu().permute(0, 2, 1), xr.grad, "dx")
+    for name, prm in blk.named_parameters():
+        check(prm.grad.cpu(), p["b." + name].grad, name)

@@ -97,32 +97,38 @@ int smt_pack_weight(const float* src, void* dst, int dtype, int n_out, int n_in,
 /* One implicit-GEMM convolution over channels-last activations (forward, or a data gradient, which
  * is the same computation on repacked weights):
  *   y[b, t*out_stride + out_offset, co] =
- *       epi( bias[co] + sum_{j<taps} sum_ci pro(x)[b, t*stride + j*dilation - padding, ci] * w[j][co][ci] )
- *   pro: rows t_in >= lens_in[b] read as 0; if act_in: relu(dropout(.)) (resnet.py:22-26)
- *   epi: if act_grad: times d relu(dropout(h))/dh at act_grad_src; rows >= lens_out[b] -> 0; + res
+ *       epi( bias[co] + sum_{j<taps} sum_ci x[b, t*stride + j*dilation - padding, ci] * w[j][co][ci] )
+ *   rows t_in >= lens_in[b] of x read as 0 (the row mask of MaskedConv1d, conv.py:7-10);
+ *   epi, in this order: if act_grad: times scale*[u != 0] with u = act_grad_src (the derivative of
+ *        relu(dropout(.)) at an activated tensor u that this library produced); rows >= lens_out[b] -> 0;
+ *        + res.
+ *   if act_out: additionally y_act = relu(dropout(y)) (resnet.py:22-26) with the counter-based
+ *        generator below; channel block [s*site_width, (s+1)*site_width) is dropout site s with key
+ *        drop_keys[s] and index i = (b*t_y + t)*site_width + (co - s*site_width).  y may be NULL then.
  * Replaces F.conv1d / F.conv_transpose1d of models/vqvae/conv.py:5-18, resnet.py:24,27,205,217 and
  * their autograd data-gradients.  c_in % 16 == 0 (bf16) or % 8 (f32). */
 typedef struct smt_conv_desc {
-  int dtype;                       /* SMT_F32 | SMT_BF16: x, w, y, res, act_grad_src */
+  int dtype;                       /* SMT_F32 | SMT_BF16: x, w, y, y_act, res, act_grad_src */
   int batch, t_in, t_out, t_y;     /* t_out: number of t computed; t_y: rows of y per batch item */
   int c_in, c_out;
   int taps, stride, dilation, padding, out_stride, out_offset;
-  int act_in, act_grad;
-  int ld_x, ld_y, ld_res, ld_act;  /* row pitches in elements */
-  uint32_t drop_key, drop_thresh16;
+  int act_out, act_grad, site_width;
+  int ld_x, ld_y, ld_res, ld_act, ld_yact;  /* row pitches in elements */
+  uint32_t drop_keys[8];
+  uint32_t drop_thresh16;
   float drop_scale;
-  int64_t bs_x, bs_y, bs_res, bs_act;  /* batch strides in elements */
-  const void* x; const void* w; const float* bias; void* y;
+  int64_t bs_x, bs_y, bs_res, bs_act, bs_yact;  /* batch strides in elements */
+  const void* x; const void* w; const float* bias; void* y; void* y_act;
   const void* res; const void* act_grad_src;
   const int* lens_in; const int* lens_out;
 } smt_conv_desc;
 int smt_conv1d_ntc(const smt_conv_desc* desc, smt_stream_t stream);
 
 /* Weight (+ bias) gradient of the same convolution:
- *   dw[j][co][ci] = sum_{b,t} dy[b, t*out_stride + out_offset, co] * pro(x)[b, t*stride + j*dil - pad, ci]
+ *   dw[j][co][ci] = sum_{b,t} dy[b, t*out_stride + out_offset, co] * x[b, t*stride + j*dil - pad, ci]
  *   db[co]        = sum_{b,t} dy[b, ., co]                                   (if dbias != NULL)
  * written in fp32 to dweight[o*stride_out + i*stride_in + tap_map[tap]*stride_tap] (torch layout).
- * `desc` is the forward descriptor with y := dy (w, bias, res, act_grad unused). */
+ * `desc` is the forward descriptor with y := dy (w, bias, res, act_*, y_act unused). */
 size_t smt_conv1d_wgrad_workspace_bytes(const smt_conv_desc* desc);
 int smt_conv1d_wgrad(const smt_conv_desc* desc, float* dweight, int64_t stride_out, int64_t stride_in,
                      int64_t stride_tap, const int* tap_map, float* dbias, void* workspace,

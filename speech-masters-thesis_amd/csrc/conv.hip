@@ -24,15 +24,15 @@
 namespace smt {
 
 struct ConvArgs {
-  const void* x; const void* w; const float* bias; void* y; const void* res; const void* gate_h;
+  const void* x; const void* w; const float* bias; void* y; const void* res; const void* gate_h; void* y_act;
   const int* lens_in; const int* lens_out;
-  long long x_bs, y_bs, res_bs, gh_bs;  // batch strides (elements)
-  int ldx, ldy, ldr, ldgh;              // row pitches (elements)
+  long long x_bs, y_bs, res_bs, gh_bs, ya_bs;  // batch strides (elements)
+  int ldx, ldy, ldr, ldgh, ldya;               // row pitches (elements)
   int B, Tin, Tout, Cin, Cout;          // Tout = output rows PER LAUNCH INDEX t (before os/oo)
   int taps, stride, dil, pad;
   int out_stride, out_offset, Ty;       // output row = t*out_stride + out_offset, Ty rows in y per batch
-  int pro_act, epi_act;                 // relu+dropout prologue / its derivative as epilogue
-  unsigned drop_key, drop_thresh16; float drop_scale;
+  int act_out, epi_act;                 // relu+dropout of the OUTPUT (second store) / its derivative as epilogue
+  unsigned drop_keys[8]; int site_width; unsigned drop_thresh16; float drop_scale;
   int tiles_per_batch;
 };
 
@@ -129,19 +129,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
       Vec<T, EPV> v;
 #pragma unroll
       for (int e = 0; e < EPV; ++e) v.v[e] = (T)0.f;
-      if (tin >= 0 && tin < len_in) {
+      if (tin >= 0 && tin < len_in)
         v = *reinterpret_cast<const Vec<T, EPV>*>(xg + (long long)tin * p.ldx + cc + cv * EPV);
-        if (p.pro_act) {
-          const unsigned long long base = ((unsigned long long)b * p.Tin + tin) * p.Cin + cc + cv * EPV;
-#pragma unroll
-          for (int e = 0; e < EPV; ++e) {
-            float fv = (float)v.v[e];
-            bool keep = drop_keep(base + e, p.drop_key, p.drop_thresh16);
-            fv = (keep && fv > 0.f) ? fv * p.drop_scale : 0.f;
-            v.v[e] = (T)fv;
-          }
-        }
-      }
       *reinterpret_cast<Vec<T, EPV>*>(lds_a + row * pitch_a + cv * EPV) = v;
     }
     // ---- K loop: taps x K-chunks, weight chunks double-buffered
@@ -183,7 +172,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
         lds_c[row * PITCH_C + col] = (T)(acc[i][n][e] + bv);
       }
   __syncthreads();
-  T* yg = reinterpret_cast<T*>(p.y) + (long long)b * p.y_bs;
+  T* yg = p.y ? reinterpret_cast<T*>(p.y) + (long long)b * p.y_bs : nullptr;
   const T* rg = p.res ? reinterpret_cast<const T*>(p.res) + (long long)b * p.res_bs : nullptr;
   const T* hg = p.epi_act ? reinterpret_cast<const T*>(p.gate_h) + (long long)b * p.gh_bs : nullptr;
   const int len_out = p.lens_out ? p.lens_out[b] : 0x7fffffff;
@@ -198,14 +187,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
     float o[EPV];
 #pragma unroll
     for (int e = 0; e < EPV; ++e) o[e] = (float)c.v[e];
-    if (p.epi_act) {
-      Vec<T, EPV> h = *reinterpret_cast<const Vec<T, EPV>*>(hg + (long long)ty * p.ldgh + col);
-      const unsigned long long base = ((unsigned long long)b * p.Ty + ty) * p.Cout + col;
+    if (p.epi_act) {  // d relu(dropout(h))/dh = scale * [u != 0] with u the stored activated tensor
+      Vec<T, EPV> u = *reinterpret_cast<const Vec<T, EPV>*>(hg + (long long)ty * p.ldgh + col);
 #pragma unroll
-      for (int e = 0; e < EPV; ++e) {
-        bool keep = drop_keep(base + e, p.drop_key, p.drop_thresh16);
-        o[e] = (keep && (float)h.v[e] > 0.f) ? o[e] * p.drop_scale : 0.f;
-      }
+      for (int e = 0; e < EPV; ++e) o[e] = ((float)u.v[e] != 0.f) ? o[e] * p.drop_scale : 0.f;
     }
     if (ty >= len_out) {
 #pragma unroll
@@ -216,10 +201,24 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
 #pragma unroll
       for (int e = 0; e < EPV; ++e) o[e] += (float)rv.v[e];
     }
-    Vec<T, EPV> out;
+    if (yg) {
+      Vec<T, EPV> out;
 #pragma unroll
-    for (int e = 0; e < EPV; ++e) out.v[e] = (T)o[e];
-    *reinterpret_cast<Vec<T, EPV>*>(yg + (long long)ty * p.ldy + col) = out;
+      for (int e = 0; e < EPV; ++e) out.v[e] = (T)o[e];
+      *reinterpret_cast<Vec<T, EPV>*>(yg + (long long)ty * p.ldy + col) = out;
+    }
+    if (p.act_out) {  // u = relu(dropout(y)), mask from the counter-based generator, fp32 before rounding
+      const int site = col / p.site_width, cs = col - site * p.site_width;
+      const unsigned key = p.drop_keys[site];
+      const unsigned long long base = ((unsigned long long)b * p.Ty + ty) * p.site_width + cs;
+      Vec<T, EPV> ua;
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) {
+        const bool keep = drop_keep(base + e, key, p.drop_thresh16);
+        ua.v[e] = (T)((keep && o[e] > 0.f) ? o[e] * p.drop_scale : 0.f);
+      }
+      *reinterpret_cast<Vec<T, EPV>*>(reinterpret_cast<T*>(p.y_act) + (long long)b * p.ya_bs + (long long)ty * p.ldya + col) = ua;
+    }
   }
 }
 
@@ -302,7 +301,7 @@ extern "C" int smt_pack_weight(const float* src, void* dst, int dtype, int n_out
 
 extern "C" int smt_conv1d_ntc(const smt_conv_desc* d, smt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  SMT_CHECK_ARG(d && d->x && d->w && d->y, "smt_conv1d_ntc: null pointer");
+  SMT_CHECK_ARG(d && d->x && d->w && (d->y || d->y_act), "smt_conv1d_ntc: null pointer");
   const int epv = d->dtype == SMT_BF16 ? 8 : 4;
   SMT_CHECK_ARG(d->dtype == SMT_BF16 || d->dtype == SMT_F32, "smt_conv1d_ntc: bad dtype");
   SMT_CHECK_ARG(d->c_in % (2 * epv) == 0, "smt_conv1d_ntc: c_in=%d must be a multiple of %d", d->c_in, 2 * epv);
@@ -312,6 +311,9 @@ extern "C" int smt_conv1d_ntc(const smt_conv_desc* d, smt_stream_t stream_) {
                 "smt_conv1d_ntc: row pitches must keep 16-byte alignment");
   SMT_CHECK_ARG(d->taps >= 1 && d->stride >= 1 && d->dilation >= 1 && d->out_stride >= 1, "smt_conv1d_ntc: bad geometry");
   SMT_CHECK_ARG(!d->act_grad || d->act_grad_src, "smt_conv1d_ntc: act_grad needs act_grad_src");
+  SMT_CHECK_ARG(!d->act_out || (d->y_act && d->site_width > 0 && d->site_width % epv == 0 && d->ld_yact % epv == 0 &&
+                                (d->c_out + d->site_width - 1) / d->site_width <= 8),
+                "smt_conv1d_ntc: act_out needs y_act and 1..8 sites of site_width channels");
   if (d->batch == 0 || d->t_out == 0) return 0;
   ConvArgs p;
   p.x = d->x; p.w = d->w; p.bias = d->bias; p.y = d->y; p.res = d->res; p.gate_h = d->act_grad_src;
@@ -321,8 +323,10 @@ extern "C" int smt_conv1d_ntc(const smt_conv_desc* d, smt_stream_t stream_) {
   p.B = d->batch; p.Tin = d->t_in; p.Tout = d->t_out; p.Cin = d->c_in; p.Cout = d->c_out;
   p.taps = d->taps; p.stride = d->stride; p.dil = d->dilation; p.pad = d->padding;
   p.out_stride = d->out_stride; p.out_offset = d->out_offset; p.Ty = d->t_y;
-  p.pro_act = d->act_in; p.epi_act = d->act_grad;
-  p.drop_key = d->drop_key; p.drop_thresh16 = d->drop_thresh16; p.drop_scale = d->drop_scale;
+  p.y_act = d->y_act; p.ya_bs = d->bs_yact; p.ldya = d->ld_yact;
+  p.act_out = d->act_out; p.epi_act = d->act_grad;
+  for (int i = 0; i < 8; ++i) p.drop_keys[i] = d->drop_keys[i];
+  p.site_width = d->site_width; p.drop_thresh16 = d->drop_thresh16; p.drop_scale = d->drop_scale;
   p.tiles_per_batch = 0;
   if (d->dtype == SMT_BF16) return launch_conv_gemm<__bf16>(p, stream);
   return launch_conv_gemm<float>(p, stream);

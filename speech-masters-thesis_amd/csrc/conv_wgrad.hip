@@ -29,7 +29,6 @@ struct WgradArgs {
   int ldx, ldy;
   int B, Tin, Tout, Ty, Cin, Cout;
   int taps, stride, dil, pad, out_stride, out_offset;
-  int pro_act; unsigned drop_key, drop_thresh16; float drop_scale;
   int rows_per_chunk, chunks_per_batch, nblk_ci, with_bias;
 };
 
@@ -97,7 +96,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
         v = *reinterpret_cast<const Vec<T, EPV>*>(dyg + (long long)ty * p.ldy + co0 + cv * EPV);
       *reinterpret_cast<Vec<T, EPV>*>(lds_dy + row * PITCH + cv * EPV) = v;
     }
-    // x tile with halo, prologue applied
+    // x tile with halo
     const int tin0 = t0 * p.stride - p.pad;
     for (int f = tid; f < rows_x * (CB / EPV); f += 256) {
       const int row = f / (CB / EPV), cv = f % (CB / EPV);
@@ -105,18 +104,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
       Vec<T, EPV> v;
 #pragma unroll
       for (int e = 0; e < EPV; ++e) v.v[e] = (T)0.f;
-      if (tin >= 0 && tin < len_in && ci0 + cv * EPV < p.Cin) {
+      if (tin >= 0 && tin < len_in && ci0 + cv * EPV < p.Cin)
         v = *reinterpret_cast<const Vec<T, EPV>*>(xg + (long long)tin * p.ldx + ci0 + cv * EPV);
-        if (p.pro_act) {
-          const unsigned long long base = ((unsigned long long)b * p.Tin + tin) * p.Cin + ci0 + cv * EPV;
-#pragma unroll
-          for (int e = 0; e < EPV; ++e) {
-            float fv = (float)v.v[e];
-            bool keep = drop_keep(base + e, p.drop_key, p.drop_thresh16);
-            v.v[e] = (T)((keep && fv > 0.f) ? fv * p.drop_scale : 0.f);
-          }
-        }
-      }
       *reinterpret_cast<Vec<T, EPV>*>(lds_x + row * PITCH + cv * EPV) = v;
     }
     __syncthreads();
@@ -278,7 +267,6 @@ extern "C" int smt_conv1d_wgrad(const smt_conv_desc* d, float* dweight, int64_t 
   a.B = d->batch; a.Tin = d->t_in; a.Tout = d->t_out; a.Ty = d->t_y; a.Cin = d->c_in; a.Cout = d->c_out;
   a.taps = d->taps; a.stride = d->stride; a.dil = d->dilation; a.pad = d->padding;
   a.out_stride = d->out_stride; a.out_offset = d->out_offset;
-  a.pro_act = d->act_in; a.drop_key = d->drop_key; a.drop_thresh16 = d->drop_thresh16; a.drop_scale = d->drop_scale;
   a.rows_per_chunk = rpc; a.chunks_per_batch = cpb; a.nblk_ci = nci; a.with_bias = 1;
   if (d->batch > 0 && d->t_out > 0) {
     dim3 grid((unsigned)(d->batch * cpb), (unsigned)(nco * nci));

@@ -68,21 +68,13 @@ class GatedHiFiBlock(nn.Module):
 
     def forward(self, x, lens, drop_seed=0):
         """x [B, T, n_in]; lens [B] valid lengths (the block's row mask)."""
-        zs = []
-        for d, branch in enumerate(self.blocks):
-            k, dil, pad = self.geometry[d]
+        if self.res_scale != 1.0:
+            raise NotImplementedError("res_scale=True is not used by the reference configs (conv.py:55)")
+        params = []
+        for branch in self.blocks:
             expand, res = getattr(branch, "0"), getattr(branch, "1").model
             conv_k, conv_1 = getattr(res, "2"), getattr(res, "5")
-            h = convops.conv1d(x, expand.weight, expand.bias, lens=lens)
-            act0 = convops.DropSpec(self.dropout, self.training, drop_seed, self.site_base + 2 * d)
-            act1 = convops.DropSpec(self.dropout, self.training, drop_seed, self.site_base + 2 * d + 1)
-            u = convops.conv1d(h, conv_k.weight, conv_k.bias, padding=pad, dilation=dil, act=act0)
-            if self.res_scale != 1.0:
-                z = h + self.res_scale * convops.conv1d(u, conv_1.weight, conv_1.bias, act=act1)
-            else:
-                z = convops.conv1d(u, conv_1.weight, conv_1.bias, act=act1, residual=h)
-            zs.append(z)
-        g = convops.gate_mix(torch.cat(zs, dim=-1), self.n_depth)
-        if self.res_scale != 1.0:
-            return x + self.res_scale * convops.conv1d(g, self.gate.weight, self.gate.bias, lens=lens)
-        return convops.conv1d(g, self.gate.weight, self.gate.bias, lens=lens, residual=x)
+            params += [expand.weight, expand.bias, conv_k.weight, conv_k.bias, conv_1.weight, conv_1.bias]
+        params += [self.gate.weight, self.gate.bias]
+        return convops.gated_hifi_block(x, lens, self.geometry, params, p_drop=self.dropout, training=self.training,
+                                        seed=drop_seed, site_base=self.site_base)

@@ -30,19 +30,20 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [("dtype", ctypes.c_int), ("batch", ctypes.c_int), ("t_in", ctypes.c_int), ("t_out", ctypes.c_int),
                 ("t_y", ctypes.c_int), ("c_in", ctypes.c_int), ("c_out", ctypes.c_int), ("taps", ctypes.c_int),
                 ("stride", ctypes.c_int), ("dilation", ctypes.c_int), ("padding", ctypes.c_int),
-                ("out_stride", ctypes.c_int), ("out_offset", ctypes.c_int), ("act_in", ctypes.c_int),
-                ("act_grad", ctypes.c_int), ("ld_x", ctypes.c_int), ("ld_y", ctypes.c_int), ("ld_res", ctypes.c_int),
-                ("ld_act", ctypes.c_int), ("drop_key", ctypes.c_uint32), ("drop_thresh16", ctypes.c_uint32),
-                ("drop_scale", ctypes.c_float), ("bs_x", ctypes.c_int64), ("bs_y", ctypes.c_int64),
-                ("bs_res", ctypes.c_int64), ("bs_act", ctypes.c_int64), ("x", ctypes.c_void_p), ("w", ctypes.c_void_p),
-                ("bias", ctypes.c_void_p), ("y", ctypes.c_void_p), ("res", ctypes.c_void_p),
+                ("out_stride", ctypes.c_int), ("out_offset", ctypes.c_int), ("act_out", ctypes.c_int),
+                ("act_grad", ctypes.c_int), ("site_width", ctypes.c_int), ("ld_x", ctypes.c_int),
+                ("ld_y", ctypes.c_int), ("ld_res", ctypes.c_int), ("ld_act", ctypes.c_int), ("ld_yact", ctypes.c_int),
+                ("drop_keys", ctypes.c_uint32 * 8), ("drop_thresh16", ctypes.c_uint32), ("drop_scale", ctypes.c_float),
+                ("bs_x", ctypes.c_int64), ("bs_y", ctypes.c_int64), ("bs_res", ctypes.c_int64),
+                ("bs_act", ctypes.c_int64), ("bs_yact", ctypes.c_int64), ("x", ctypes.c_void_p), ("w", ctypes.c_void_p),
+                ("bias", ctypes.c_void_p), ("y", ctypes.c_void_p), ("y_act", ctypes.c_void_p), ("res", ctypes.c_void_p),
                 ("act_grad_src", ctypes.c_void_p), ("lens_in", ctypes.c_void_p), ("lens_out", ctypes.c_void_p)]
 
 
 @dataclass
 class DropSpec:
-    """relu(dropout(x)) prologue of a conv (reference models/vqvae/resnet.py:22-26) with the
-    counter-based generator of include/smt_hip.h ("dropout")."""
+    """relu(dropout(.)) of a conv OUTPUT (reference models/vqvae/resnet.py:22-26), produced in the
+    conv's epilogue with the counter-based generator of include/smt_hip.h ("dropout")."""
     p: float
     training: bool
     seed: int = 0
@@ -94,8 +95,14 @@ def _pack(weight, dtype, n_out, n_in, s_out, s_in, s_tap, tap_map):
     return dst
 
 
+def _tag(desc):
+    return f"k{desc.taps}d{desc.dilation}s{desc.stride}o{desc.out_stride}_c{desc.c_in}x{desc.c_out}"
+
+
 def _launch(desc, name, flops=0.0, nbytes=0.0):
     dtype = "bf16" if desc.dtype == SMT_BF16 else "f32"
+    if profiler.DETAIL:
+        name = name + "_" + _tag(desc)
     with profiler.region(name, nbytes=nbytes, flops=flops, bound="mfma", dtype=dtype):
         N.check(N.lib().smt_conv1d_ntc(ctypes.byref(desc), N.stream_ptr()), "smt_conv1d_ntc")
 
@@ -122,15 +129,16 @@ def _phases(kernel, stride, padding):
     return out
 
 
-def _base_desc(x, y, lens_in, c_in, c_out, taps, stride, dil, pad, t_out, out_stride=1, out_offset=0):
+def _base_desc(x, y, lens_in, c_in, c_out, taps, stride, dil, pad, t_out, out_stride=1, out_offset=0, t_y=None):
     d = ConvDesc()
     d.dtype = _DT[x.dtype]
-    d.batch, d.t_in, d.t_out, d.t_y = x.shape[0], x.shape[1], t_out, y.shape[1]
+    d.batch, d.t_in, d.t_out, d.t_y = x.shape[0], x.shape[1], t_out, (y.shape[1] if t_y is None else t_y)
     d.c_in, d.c_out = c_in, c_out
     d.taps, d.stride, d.dilation, d.padding = taps, stride, dil, pad
     d.out_stride, d.out_offset = out_stride, out_offset
     d.x, d.bs_x, d.ld_x = _geom(x)
-    d.y, d.bs_y, d.ld_y = _geom(y)
+    if y is not None:
+        d.y, d.bs_y, d.ld_y = _geom(y)
     d.lens_in = _p(lens_in)
     d.drop_scale = 1.0
     return d
@@ -142,39 +150,67 @@ def _wgrad(desc, dweight, s_out, s_in, s_tap, tap_map, dbias):
     ws = N.workspace.get(ws_bytes, dweight.device)
     arr = (ctypes.c_int * len(tap_map))(*tap_map)
     dtype = "bf16" if desc.dtype == SMT_BF16 else "f32"
-    with profiler.region("conv_wgrad", flops=_conv_flops(desc), bound="mfma", dtype=dtype):
+    name = "conv_wgrad" + ("_" + _tag(desc) if profiler.DETAIL else "")
+    with profiler.region(name, flops=_conv_flops(desc), bound="mfma", dtype=dtype):
         N.check(lib.smt_conv1d_wgrad(ctypes.byref(desc), _p(dweight), s_out, s_in, s_tap, arr, _p(dbias), _p(ws),
                                      ws.numel(), N.stream_ptr()), "smt_conv1d_wgrad")
 
 
+def _set_act_out(d, u, keys, thresh, scale, site_width):
+    d.act_out, d.site_width = 1, site_width
+    d.y_act, d.bs_yact, d.ld_yact = _geom(u)
+    for i, k in enumerate(keys):
+        d.drop_keys[i] = k
+    d.drop_thresh16, d.drop_scale = thresh, scale
+
+
+def _set_act_grad(d, u, scale):
+    """Data-gradient epilogue: times d relu(dropout(h))/dh = scale * [u != 0]."""
+    d.act_grad = 1
+    d.act_grad_src, d.bs_act, d.ld_act = _geom(u)
+    d.drop_scale = scale
+
+
+def _dgrad_stride1(dy, weight_packed_bwd, dx, k, dilation, padding):
+    c_in, c_out = dx.shape[2], dy.shape[2]
+    d = _base_desc(dy, dx, None, c_out, c_in, k, 1, dilation, (k - 1) * dilation - padding, dx.shape[1])
+    d.w = _p(weight_packed_bwd)
+    return d
+
+
+def _pack_fwd(weight, dtype):
+    c_out, c_in, k = weight.shape
+    return _pack(weight, dtype, c_out, c_in, c_in * k, k, 1, list(range(k)))
+
+
+def _pack_bwd(weight, dtype):
+    """[tap][ci][co] with flipped taps: the data gradient of a stride-1 conv is a conv with these."""
+    c_out, c_in, k = weight.shape
+    return _pack(weight, dtype, c_in, c_out, k, c_in * k, 1, [k - 1 - j for j in range(k)])
+
+
 class _Conv1d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, lens, stride, padding, dilation, act):
+    def forward(ctx, x, weight, bias, residual, lens, stride, padding, dilation):
         b, t_in, c_in = x.shape
         c_out, _, k = weight.shape
         t_out = (t_in + 2 * padding - dilation * (k - 1) - 1) // stride + 1
         y = torch.empty(b, t_out, c_out, dtype=x.dtype, device=x.device)
         lens32 = _i32(lens)
-        wp = _pack(weight, x.dtype, c_out, c_in, c_in * k, k, 1, list(range(k)))
+        wp = _pack_fwd(weight, x.dtype)
         d = _base_desc(x, y, lens32, c_in, c_out, k, stride, dilation, padding, t_out)
         d.w, d.bias = _p(wp), _p(bias)
-        key = thresh = 0
-        scale = 1.0
-        if act is not None:
-            key, thresh, scale = act.params()
-            d.act_in, d.drop_key, d.drop_thresh16, d.drop_scale = 1, key, thresh, scale
         if residual is not None:
             d.res, d.bs_res, d.ld_res = _geom(residual)
         _launch(d, "conv_fwd", _conv_flops(d), _conv_bytes(d, x.element_size()))
         ctx.save_for_backward(x, weight, lens32 if lens32 is not None else torch.empty(0))
-        ctx.cfg = (stride, padding, dilation, act is not None, key, thresh, scale, lens is not None,
-                   residual is not None, bias is not None)
+        ctx.cfg = (stride, padding, dilation, lens is not None, residual is not None, bias is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, weight, lens32 = ctx.saved_tensors
-        stride, padding, dilation, has_act, key, thresh, scale, has_lens, has_res, has_bias = ctx.cfg
+        stride, padding, dilation, has_lens, has_res, has_bias = ctx.cfg
         lens32 = lens32 if has_lens else None
         b, t_in, c_in = x.shape
         c_out, _, k = weight.shape
@@ -185,10 +221,8 @@ class _Conv1d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty(b, t_in, c_in, dtype=x.dtype, device=x.device)
             if stride == 1:
-                wb = _pack(weight, x.dtype, c_in, c_out, k, c_in * k, 1, [k - 1 - j for j in range(k)])
-                d = _base_desc(dy, dx, None, c_out, c_in, k, 1, dilation, (k - 1) * dilation - padding, t_in)
-                d.w = _p(wb)
-                _finish_dx(d, x, lens32, has_act, key, thresh, scale)
+                d = _dgrad_stride1(dy, _pack_bwd(weight, x.dtype), dx, k, dilation, padding)
+                d.lens_out = _p(lens32)
                 _launch(d, "conv_dgrad", _conv_flops(d), _conv_bytes(d, x.element_size()))
             else:
                 for ph, (taps, pad_eff) in enumerate(_phases(k, stride, padding)):
@@ -198,34 +232,22 @@ class _Conv1d(torch.autograd.Function):
                     wb = _pack(weight, x.dtype, c_in, c_out, k, c_in * k, 1, taps)
                     d = _base_desc(dy, dx, None, c_out, c_in, len(taps), 1, 1, pad_eff, n_ph, stride, ph)
                     d.w = _p(wb)
-                    _finish_dx(d, x, lens32, has_act, key, thresh, scale)
+                    d.lens_out = _p(lens32)
                     _launch(d, "conv_dgrad", _conv_flops(d), _conv_bytes(d, x.element_size()))
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
             db = torch.empty(c_out, dtype=torch.float32, device=x.device)
             d = _base_desc(x, dy, lens32, c_in, c_out, k, stride, dilation, padding, t_out)
-            if has_act:
-                d.act_in, d.drop_key, d.drop_thresh16, d.drop_scale = 1, key, thresh, scale
             _wgrad(d, dw, c_in * k, k, 1, list(range(k)), db)
             if not has_bias:
                 db = None
-        return dx, dw, db, (dy if has_res else None), None, None, None, None, None
+        return dx, dw, db, (dy if has_res else None), None, None, None, None
 
 
-def _finish_dx(d, x, lens32, has_act, key, thresh, scale):
-    """Epilogue of a data gradient: derivative of the forward prologue at the saved input."""
-    if has_act:
-        d.act_grad = 1
-        d.act_grad_src, d.bs_act, d.ld_act = _geom(x)
-        d.drop_key, d.drop_thresh16, d.drop_scale = key, thresh, scale
-    d.lens_out = _p(lens32)
-
-
-def conv1d(x, weight, bias, *, stride=1, padding=0, dilation=1, lens=None, act: Optional[DropSpec] = None,
-           residual=None):
-    """y[b,t,:] = bias + sum_j W_j . pro(x)[b, t*stride + j*dilation - padding, :] (+ residual);
-    ``weight`` keeps torch's Conv1d layout [Cout, Cin, k] (checkpoint compatibility)."""
-    return _Conv1d.apply(x, weight, bias, residual, lens, stride, padding, dilation, act)
+def conv1d(x, weight, bias, *, stride=1, padding=0, dilation=1, lens=None, residual=None):
+    """y[b,t,:] = bias + sum_j W_j . x[b, t*stride + j*dilation - padding, :] (+ residual), rows
+    t >= lens[b] of x read as zero; ``weight`` keeps torch's Conv1d layout [Cout, Cin, k]."""
+    return _Conv1d.apply(x, weight, bias, residual, lens, stride, padding, dilation)
 
 
 class _ConvTranspose1d(torch.autograd.Function):
@@ -389,3 +411,143 @@ class _ConvOut(torch.autograd.Function):
 def conv_out(x, weight, bias, *, lens=None):
     """Final decoder projection to one channel on masked rows: [B, T, C] -> fp32 [B, T]."""
     return _ConvOut.apply(x, weight, bias, lens)
+
+
+# ----------------------------------------------------------------------------------------------
+# GatedHiFiBlock as ONE autograd node (reference models/vqvae/resnet.py:184-241).
+#
+# forward                                             tensors kept for backward
+#   h1|u1 = K1cat(x*mask)        one GEMM, N = D*2w   u1   (u = relu(dropout(h)), written by the
+#   u2_d  = act(K2_d(u1_d))      dilated, per branch  u2    producing conv's epilogue; h2 is never
+#   z_d   = h1_d + K3_d(u2_d)    1x1 + residual       z     stored, h1 only until z is formed)
+#   g     = gate_mix(z)                               g
+#   out   = x + Kg(g*mask)                            x
+# backward: every data gradient is the same GEMM kernel on repacked weights with the activation
+# derivative (scale * [u != 0]), the row mask and the residual-gradient add fused in its epilogue.
+# ----------------------------------------------------------------------------------------------
+class _GatedHiFi(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, lens, geometry, drop, n_params, *params):
+        """params = per branch (w1, b1, w2, b2, w3, b3) * depth + (wg, bg); drop = (p, training, seed, site_base)."""
+        depth = len(geometry)
+        b, t, w = x.shape
+        c2 = 2 * w
+        dt, dev = x.dtype, x.device
+        lens32 = _i32(lens)
+        p_drop, training, seed, site_base = drop
+        specs = [[DropSpec(p_drop, training, seed, site_base + 2 * d + s).params() for s in (0, 1)] for d in range(depth)]
+        thresh, scale = specs[0][0][1], specs[0][0][2]
+        br = [params[6 * d:6 * d + 6] for d in range(depth)]
+        wg, bg = params[6 * depth], params[6 * depth + 1]
+
+        # K1 for all branches at once
+        w1cat = torch.cat([p[0] for p in br], dim=0)
+        b1cat = torch.cat([p[1] for p in br], dim=0)
+        h1 = torch.empty(b, t, depth * c2, dtype=dt, device=dev)
+        u1 = torch.empty_like(h1)
+        d1 = _base_desc(x, h1, lens32, w, depth * c2, 1, 1, 1, 0, t)
+        d1.w, d1.bias = _p(_pack_fwd(w1cat, dt)), _p(b1cat)
+        _set_act_out(d1, u1, [specs[d][0][0] for d in range(depth)], thresh, scale, c2)
+        _launch(d1, "conv_fwd", _conv_flops(d1), _conv_bytes(d1, x.element_size()))
+
+        u2 = torch.empty_like(h1)
+        z = torch.empty_like(h1)
+        for d, (k, dil, pad) in enumerate(geometry):
+            sl = slice(d * c2, (d + 1) * c2)
+            u1_d, u2_d = u1[:, :, sl], u2[:, :, sl]
+            d2 = _base_desc(u1_d, None, None, c2, c2, k, 1, dil, pad, t, t_y=t)
+            d2.w, d2.bias = _p(_pack_fwd(br[d][2], dt)), _p(br[d][3])
+            _set_act_out(d2, u2_d, [specs[d][1][0]], thresh, scale, c2)
+            _launch(d2, "conv_fwd", _conv_flops(d2), _conv_bytes(d2, x.element_size()))
+        for d in range(depth):
+            sl = slice(d * c2, (d + 1) * c2)
+            d3 = _base_desc(u2[:, :, sl], z[:, :, sl], None, c2, c2, 1, 1, 1, 0, t)
+            d3.w, d3.bias = _p(_pack_fwd(br[d][4], dt)), _p(br[d][5])
+            d3.res, d3.bs_res, d3.ld_res = _geom(h1[:, :, sl])
+            _launch(d3, "conv_fwd", _conv_flops(d3), _conv_bytes(d3, x.element_size()))
+        del h1
+        g = torch.empty(b, t, w, dtype=dt, device=dev)
+        with profiler.region("gate_mix_fwd", nbytes=z.numel() * z.element_size() * 1.125, bound="hbm"):
+            N.check(N.lib().smt_gate_mix_fwd(_p(z), _p(g), _DT[dt], b * t, w, depth, depth * c2, w, N.stream_ptr()),
+                    "smt_gate_mix_fwd")
+        out = torch.empty_like(x)
+        dg_ = _base_desc(g, out, lens32, w, w, 1, 1, 1, 0, t)
+        dg_.w, dg_.bias = _p(_pack_fwd(wg, dt)), _p(bg)
+        dg_.res, dg_.bs_res, dg_.ld_res = _geom(x)
+        _launch(dg_, "conv_fwd", _conv_flops(dg_), _conv_bytes(dg_, x.element_size()))
+
+        ctx.save_for_backward(x, lens32 if lens32 is not None else torch.empty(0), u1, u2, z, g, *params)
+        ctx.cfg = (geometry, scale, lens is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, lens32, u1, u2, z, g, *params = ctx.saved_tensors
+        geometry, scale, has_lens = ctx.cfg
+        lens32 = lens32 if has_lens else None
+        depth = len(geometry)
+        b, t, w = x.shape
+        c2 = 2 * w
+        dt, dev = x.dtype, x.device
+        br = [params[6 * d:6 * d + 6] for d in range(depth)]
+        wg, bg = params[6 * depth], params[6 * depth + 1]
+        dout = dout.contiguous()
+        grads = [None] * len(params)
+
+        def f32(shape):
+            return torch.empty(shape, dtype=torch.float32, device=dev)
+
+        # gate conv: dg = (dout . Wg^T) * mask ; dWg, dbg
+        dg = torch.empty_like(g)
+        d = _dgrad_stride1(dout, _pack_bwd(wg, dt), dg, 1, 1, 0)
+        d.lens_out = _p(lens32)
+        _launch(d, "conv_dgrad", _conv_flops(d), _conv_bytes(d, x.element_size()))
+        grads[6 * depth], grads[6 * depth + 1] = torch.empty_like(wg), f32(bg.shape)
+        _wgrad(_base_desc(g, dout, lens32, w, w, 1, 1, 1, 0, t), grads[6 * depth], w, 1, 1, [0], grads[6 * depth + 1])
+
+        dz = torch.empty_like(z)
+        with profiler.region("gate_mix_bwd", nbytes=z.numel() * z.element_size() * 2.125, bound="hbm"):
+            N.check(N.lib().smt_gate_mix_bwd(_p(z), _p(dg), _p(dz), _DT[dt], b * t, w, depth, depth * c2, w, depth * c2,
+                                             N.stream_ptr()), "smt_gate_mix_bwd")
+        del dg
+        dh1 = torch.empty_like(z)
+        dh2 = torch.empty(b, t, c2, dtype=dt, device=dev)     # one branch at a time
+        for dd, (k, dil, pad) in enumerate(geometry):
+            sl = slice(dd * c2, (dd + 1) * c2)
+            w1, b1, w2, b2, w3, b3 = br[dd]
+            dz_d, u1_d, u2_d = dz[:, :, sl], u1[:, :, sl], u2[:, :, sl]
+            # K3: dh2 = (dz_d . W3^T) * act'(u2);  dW3 = u2^T dz_d
+            d = _dgrad_stride1(dz_d, _pack_bwd(w3, dt), dh2, 1, 1, 0)
+            _set_act_grad(d, u2_d, scale)
+            _launch(d, "conv_dgrad", _conv_flops(d), _conv_bytes(d, x.element_size()))
+            grads[6 * dd + 4], grads[6 * dd + 5] = torch.empty_like(w3), f32(b3.shape)
+            _wgrad(_base_desc(u2_d, dz_d, None, c2, c2, 1, 1, 1, 0, t), grads[6 * dd + 4], c2, 1, 1, [0],
+                   grads[6 * dd + 5])
+            # K2: dh1_d = (dh2 * W2^T) * act'(u1) + dz_d;  dW2 = u1^T dh2
+            d = _dgrad_stride1(dh2, _pack_bwd(w2, dt), dh1[:, :, sl], k, dil, pad)
+            _set_act_grad(d, u1_d, scale)
+            d.res, d.bs_res, d.ld_res = _geom(dz_d)
+            _launch(d, "conv_dgrad", _conv_flops(d), _conv_bytes(d, x.element_size()))
+            grads[6 * dd + 2], grads[6 * dd + 3] = torch.empty_like(w2), f32(b2.shape)
+            _wgrad(_base_desc(u1_d, dh2, None, c2, c2, k, 1, dil, pad, t), grads[6 * dd + 2], c2 * k, k, 1,
+                   list(range(k)), grads[6 * dd + 3])
+        del dz, dh2
+        # K1cat: dx = (dh1 . W1cat^T) * mask + dout ; dW1cat
+        w1cat = torch.cat([p[0] for p in br], dim=0)
+        dx = torch.empty_like(x)
+        d = _dgrad_stride1(dh1, _pack_bwd(w1cat, dt), dx, 1, 1, 0)
+        d.lens_out = _p(lens32)
+        d.res, d.bs_res, d.ld_res = _geom(dout)
+        _launch(d, "conv_dgrad", _conv_flops(d), _conv_bytes(d, x.element_size()))
+        dw1cat, db1cat = torch.empty_like(w1cat), f32((depth * c2,))
+        _wgrad(_base_desc(x, dh1, lens32, w, depth * c2, 1, 1, 1, 0, t), dw1cat, w, 1, 1, [0], db1cat)
+        for dd in range(depth):
+            grads[6 * dd] = dw1cat[dd * c2:(dd + 1) * c2]
+            grads[6 * dd + 1] = db1cat[dd * c2:(dd + 1) * c2]
+        return (dx, None, None, None, None, *grads)
+
+
+def gated_hifi_block(x, lens, geometry, params, *, p_drop, training, seed, site_base):
+    """x [B, T, w]; geometry = [(k, dilation, padding)] per branch; params = flat list
+    (w1, b1, w2, b2, w3, b3) per branch followed by (gate.weight, gate.bias)."""
+    return _GatedHiFi.apply(x, lens, tuple(geometry), (p_drop, training, seed, site_base), len(params), *params)

@@ -15,6 +15,7 @@ PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
 DOMINANT = "vq_forward"      # kernel group reported under "roofline" (updated as kernels land)
 
 _enabled = False
+DETAIL = bool(int(__import__("os").environ.get("SMT_PROFILE_DETAIL", "0")))  # per-geometry kernel names
 _records = defaultdict(list)  # name -> [(start, end, bytes, flops, bound, dtype)]
 
 

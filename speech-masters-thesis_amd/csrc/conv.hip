@@ -17,6 +17,7 @@
 // The accumulator tile goes back through LDS so that the epilogue (bias, activation gradient, row
 // mask, residual) and the stores are fully coalesced 16-byte accesses.
 #include <algorithm>
+#include <cstdlib>
 
 #include "smt_common.h"
 #include "conv_common.h"
@@ -34,6 +35,7 @@ struct ConvArgs {
   int act_out, epi_act;                 // relu+dropout of the OUTPUT (second store) / its derivative as epilogue
   unsigned drop_keys[8]; int site_width; unsigned drop_thresh16; float drop_scale;
   int tiles_per_batch;
+  int dbg;  // ablation switches (SMT_CONV_DBG): 1 no A loads, 2 no W loads, 4 no MFMA, 8 no stores
 };
 
 template <typename T>
@@ -54,23 +56,32 @@ __device__ __forceinline__ void mma_step<float>(const float* a, const float* b, 
   acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
 }
 
-// BN = 128 (NW = 2 column tiles per wave) or 64 (NW = 1); waves 2 (rows) x 2 (cols)
-template <typename T, int BN>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
+// Waves are arranged 2 (rows) x WN (cols): NT = 256 threads -> WN = 2, NT = 512 -> WN = 4 (two waves per
+// SIMD, so one wave's staging / address arithmetic hides under the other's MFMAs).
+template <typename T, int BN, int NT>
+__global__ __launch_bounds__(NT) void conv_gemm_kernel(ConvArgs p) {
   constexpr int EPV = Tr<T>::EPV, CCH = Tr<T>::CCH, KC = Tr<T>::KC, BM = Tr<T>::BM;
   constexpr int MW = BM / 64;           // 32-row tiles per wave (bf16: 2, fp32: 1)
-  constexpr int NW = BN / 64;           // 32-col tiles per wave
+  constexpr int WN = NT / 128;          // wave columns
+  constexpr int NW = BN / (32 * WN);    // 32-col tiles per wave
   constexpr int PITCH_W = KC + EPV;
   constexpr int PITCH_C = BN + EPV;
   constexpr int WVEC = BN * KC / EPV;   // 16-byte vectors per weight chunk
-  constexpr int WST = WVEC / 256;
+  constexpr int WST = WVEC / NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, hh = lane >> 5;
-  const int b = blockIdx.x / p.tiles_per_batch;
-  const int t0 = (blockIdx.x % p.tiles_per_batch) * BM;
+  // XCD-aware mapping (cdna guide T1): workgroups b and b+8 share an XCD/L2, so give every XCD a
+  // CONTIGUOUS run of row tiles -- neighbouring tiles share their halo rows and the weights in L2.
+  const int ntiles = p.tiles_per_batch * p.B;
+  const int per_xcd = (ntiles + 7) / 8;
+  const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (tile >= ntiles) return;
+  if (p.dbg & 16) return;
+  const int b = tile / p.tiles_per_batch;
+  const int t0 = (tile % p.tiles_per_batch) * BM;
   const int n0 = blockIdx.y * BN;
 
   const int rows_in = (BM - 1) * p.stride + (p.taps - 1) * p.dil + 1;
@@ -94,27 +105,28 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][n][e] = 0.f;
 
-  Vec<T, EPV> wst[WST];
-  auto w_load = [&](int j, int ci0) {  // chunk rows co = n0.., cols ci = ci0..ci0+KC
+  // weight chunk staging: two register sets so that chunk s+2 is in flight while chunk s is consumed
+  Vec<T, EPV> wst0[WST], wst1[WST];
+  auto w_load = [&](Vec<T, EPV>* wst, int j, int ci0) {  // chunk rows co = n0.., cols ci = ci0..ci0+KC
 #pragma unroll
     for (int s = 0; s < WST; ++s) {
-      int f = tid + 256 * s;
+      int f = tid + NT * s;
       int co = f / (KC / EPV), cv = f % (KC / EPV);
       int ci = ci0 + cv * EPV;
       Vec<T, EPV> v;
 #pragma unroll
       for (int e = 0; e < EPV; ++e) v.v[e] = (T)0.f;
-      if (n0 + co < p.Cout && ci < p.Cin)
+      if (n0 + co < p.Cout && ci < p.Cin && !(p.dbg & 2))
         v = *reinterpret_cast<const Vec<T, EPV>*>(wg + ((size_t)j * p.Cout + n0 + co) * p.Cin + ci);
       wst[s] = v;
     }
   };
-  auto w_store = [&](int buf) {
+  auto w_store = [&](const Vec<T, EPV>* wst, int buf) {
 #pragma unroll
     for (int s = 0; s < WST; ++s) {
-      int f = tid + 256 * s;
+      int f = tid + NT * s;
       int co = f / (KC / EPV), cv = f % (KC / EPV);
-      *reinterpret_cast<Vec<T, EPV>*>(lds_w + (size_t)buf * BN * PITCH_W + co * PITCH_W + cv * EPV) = wst[s];
+      if (!(p.dbg & 128)) *reinterpret_cast<Vec<T, EPV>*>(lds_w + (size_t)buf * BN * PITCH_W + co * PITCH_W + cv * EPV) = wst[s];
     }
   };
 
@@ -123,53 +135,98 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
     __syncthreads();  // previous chunk's readers are done with lds_a / lds_w
     // ---- stage the haloed input tile (this channel chunk), prologue applied once per element
     const int vpr = cch / EPV;
-    for (int f = tid; f < rows_in * vpr; f += 256) {
-      const int row = f / vpr, cv = f % vpr;
-      const int tin = tin0 + row;
-      Vec<T, EPV> v;
+    const int vshift = 31 - __builtin_clz(vpr);   // vpr is a power of two (checked on the host)
+    {
+      // batches of UB independent 16-byte loads per thread, THEN the LDS stores: a load->store loop
+      // would expose one full memory latency per vector
+      constexpr int UB = 8;
+      const int total = rows_in * vpr;
+      for (int f0 = tid; f0 < total; f0 += NT * UB) {
+        Vec<T, EPV> v[UB];
 #pragma unroll
-      for (int e = 0; e < EPV; ++e) v.v[e] = (T)0.f;
-      if (tin >= 0 && tin < len_in)
-        v = *reinterpret_cast<const Vec<T, EPV>*>(xg + (long long)tin * p.ldx + cc + cv * EPV);
-      *reinterpret_cast<Vec<T, EPV>*>(lds_a + row * pitch_a + cv * EPV) = v;
+        for (int u = 0; u < UB; ++u) {
+          const int f = f0 + NT * u;
+          const int row = f >> vshift, cv = f & (vpr - 1);
+          const int tin = tin0 + row;
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) v[u].v[e] = (T)0.f;
+          if (f < total && tin >= 0 && tin < len_in && !(p.dbg & 1))
+            v[u] = *reinterpret_cast<const Vec<T, EPV>*>(xg + (long long)tin * p.ldx + cc + cv * EPV);
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int f = f0 + NT * u;
+          const int row = f >> vshift, cv = f & (vpr - 1);
+          if (f < total && !(p.dbg & 64)) *reinterpret_cast<Vec<T, EPV>*>(lds_a + row * pitch_a + cv * EPV) = v[u];
+        }
+      }
     }
-    // ---- K loop: taps x K-chunks, weight chunks double-buffered
+    // ---- K loop: taps x K-chunks.  LDS weight buffers alternate; global loads run two chunks ahead
     const int nkc = (cch + KC - 1) / KC;
     const int nsteps = p.taps * nkc;
-    w_load(0, cc);
-    w_store(0);
-    __syncthreads();
-    for (int s = 0; s < nsteps; ++s) {
+    auto compute = [&](int s) {
       const int j = s / nkc, kc = s % nkc;
-      const int buf = s & 1;
-      if (s + 1 < nsteps) w_load((s + 1) / nkc, cc + ((s + 1) % nkc) * KC);
       const int kvalid = min(KC, cch - kc * KC);
       const T* abase = lds_a + (wm * (BM / 2) * p.stride + j * p.dil + r * p.stride) * pitch_a + kc * KC + hh * EPV;
-      const T* bbase = lds_w + (size_t)buf * BN * PITCH_W + (wn * (BN / 2) + r) * PITCH_W + hh * EPV;
-      for (int kk = 0; kk < kvalid; kk += 2 * EPV) {
+      const T* bbase = lds_w + (size_t)(s & 1) * BN * PITCH_W + (wn * (BN / WN) + r) * PITCH_W + hh * EPV;
+      const int a_step = 32 * p.stride * pitch_a;
+      if (p.dbg & 4) return;
+      if (kvalid == KC) {  // full chunk: constant trip count so the LDS reads are scheduled ahead of the MFMAs
 #pragma unroll
-        for (int i = 0; i < MW; ++i)
+        for (int kk = 0; kk < KC; kk += 2 * EPV) {
 #pragma unroll
-          for (int n = 0; n < NW; ++n)
-            mma_step<T>(abase + i * 32 * p.stride * pitch_a + kk, bbase + n * 32 * PITCH_W + kk, acc[i][n]);
+          for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int n = 0; n < NW; ++n)
+              mma_step<T>(abase + i * a_step + kk, bbase + n * 32 * PITCH_W + kk, acc[i][n]);
+        }
+      } else {
+        for (int kk = 0; kk < kvalid; kk += 2 * EPV) {
+#pragma unroll
+          for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int n = 0; n < NW; ++n)
+              mma_step<T>(abase + i * a_step + kk, bbase + n * 32 * PITCH_W + kk, acc[i][n]);
+        }
       }
-      if (s + 1 < nsteps) w_store(buf ^ 1);
+    };
+    w_load(wst0, 0, cc);
+    if (nsteps > 1) w_load(wst1, 1 / nkc, cc + (1 % nkc) * KC);
+    w_store(wst0, 0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; s += 2) {
+      // even step: chunk s is in LDS[0]; chunk s+1 sits in wst1; fetch chunk s+2 into wst0
+      if (s + 2 < nsteps) w_load(wst0, (s + 2) / nkc, cc + ((s + 2) % nkc) * KC);
+      compute(s);
+      if (s + 1 < nsteps) w_store(wst1, 1);
+      __syncthreads();
+      if (s + 1 >= nsteps) break;
+      // odd step: chunk s+1 is in LDS[1]; chunk s+2 sits in wst0; fetch chunk s+3 into wst1
+      if (s + 3 < nsteps) w_load(wst1, (s + 3) / nkc, cc + ((s + 3) % nkc) * KC);
+      compute(s + 1);
+      if (s + 2 < nsteps) w_store(wst0, 0);
       __syncthreads();
     }
   }
 
+  if (p.dbg & 32) return;
   // ---- accumulators -> LDS (element type T) -> coalesced epilogue
+  float bvals[NW];
+#pragma unroll
+  for (int n = 0; n < NW; ++n) {
+    const int col = n0 + wn * (BN / WN) + n * 32 + r;
+    bvals[n] = (p.bias && col < p.Cout) ? p.bias[col] : 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < MW; ++i)
 #pragma unroll
     for (int n = 0; n < NW; ++n)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        int row = wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-        int col = wn * (BN / 2) + n * 32 + r;
+        const int row = wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        const int col = wn * (BN / WN) + n * 32 + r;
         // bias joins in fp32 before the (single, for residual-free layers) rounding to T
-        float bv = (p.bias && n0 + col < p.Cout) ? p.bias[n0 + col] : 0.f;
-        lds_c[row * PITCH_C + col] = (T)(acc[i][n][e] + bv);
+        lds_c[row * PITCH_C + col] = (T)(acc[i][n][e] + bvals[n]);
       }
   __syncthreads();
   T* yg = p.y ? reinterpret_cast<T*>(p.y) + (long long)b * p.y_bs : nullptr;
@@ -177,45 +234,62 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
   const T* hg = p.epi_act ? reinterpret_cast<const T*>(p.gate_h) + (long long)b * p.gh_bs : nullptr;
   const int len_out = p.lens_out ? p.lens_out[b] : 0x7fffffff;
   constexpr int CV = BN / EPV;
-  for (int f = tid; f < BM * CV; f += 256) {
-    const int row = f / CV, cv = f % CV;
-    const int t = t0 + row, col = n0 + cv * EPV;
-    if (t >= p.Tout || col >= p.Cout) continue;
+  constexpr int NE = BM * CV / NT;    // vectors per thread
+  // A full tile (the overwhelmingly common case) needs no per-vector bounds logic: every condition
+  // below is then wave-uniform and the eight vectors of a thread are independent straight-line code.
+  const bool full = (t0 + BM <= p.Tout) && (n0 + BN <= p.Cout) && ((t0 + BM - 1) * p.out_stride + p.out_offset < p.Ty);
+  const int cv0 = tid % CV, row0 = tid / CV;      // this thread's column vector; rows row0 + it*(NT/CV)
+  const int col = n0 + cv0 * EPV;
+  Vec<T, EPV> rv[NE], uv[NE];
+  bool okv[NE];
+#pragma unroll
+  for (int it = 0; it < NE; ++it) {
+    const int t = t0 + row0 + it * (NT / CV);
     const int ty = t * p.out_stride + p.out_offset;
-    if (ty >= p.Ty) continue;
-    Vec<T, EPV> c = *reinterpret_cast<const Vec<T, EPV>*>(lds_c + row * PITCH_C + cv * EPV);
+    okv[it] = full || ((t < p.Tout) && (col < p.Cout) && (ty < p.Ty));
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) { rv[it].v[e] = (T)0.f; uv[it].v[e] = (T)0.f; }
+    if (rg && okv[it]) rv[it] = *reinterpret_cast<const Vec<T, EPV>*>(rg + (long long)ty * p.ldr + col);
+    if (p.epi_act && okv[it]) uv[it] = *reinterpret_cast<const Vec<T, EPV>*>(hg + (long long)ty * p.ldgh + col);
+  }
+  const int site = p.act_out ? col / p.site_width : 0;
+  const unsigned key = p.drop_keys[site & 7];
+  const int cs = col - site * (p.act_out ? p.site_width : 0);
+#pragma unroll
+  for (int it = 0; it < NE; ++it) {
+    const int row = row0 + it * (NT / CV);
+    const int ty = (t0 + row) * p.out_stride + p.out_offset;
+    Vec<T, EPV> c = *reinterpret_cast<const Vec<T, EPV>*>(lds_c + row * PITCH_C + cv0 * EPV);
     float o[EPV];
 #pragma unroll
     for (int e = 0; e < EPV; ++e) o[e] = (float)c.v[e];
     if (p.epi_act) {  // d relu(dropout(h))/dh = scale * [u != 0] with u the stored activated tensor
-      Vec<T, EPV> u = *reinterpret_cast<const Vec<T, EPV>*>(hg + (long long)ty * p.ldgh + col);
 #pragma unroll
-      for (int e = 0; e < EPV; ++e) o[e] = ((float)u.v[e] != 0.f) ? o[e] * p.drop_scale : 0.f;
+      for (int e = 0; e < EPV; ++e) o[e] = ((float)uv[it].v[e] != 0.f) ? o[e] * p.drop_scale : 0.f;
     }
-    if (ty >= len_out) {
-#pragma unroll
-      for (int e = 0; e < EPV; ++e) o[e] = 0.f;
-    }
+    const float keep_row = (ty >= len_out) ? 0.f : 1.f;
     if (rg) {
-      Vec<T, EPV> rv = *reinterpret_cast<const Vec<T, EPV>*>(rg + (long long)ty * p.ldr + col);
 #pragma unroll
-      for (int e = 0; e < EPV; ++e) o[e] += (float)rv.v[e];
+      for (int e = 0; e < EPV; ++e) o[e] = fmaf(o[e], keep_row, (float)rv[it].v[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) o[e] *= keep_row;
     }
-    if (yg) {
+    if (yg && okv[it] && !(p.dbg & 8)) {
       Vec<T, EPV> out;
 #pragma unroll
       for (int e = 0; e < EPV; ++e) out.v[e] = (T)o[e];
       *reinterpret_cast<Vec<T, EPV>*>(yg + (long long)ty * p.ldy + col) = out;
     }
-    if (p.act_out) {  // u = relu(dropout(y)), mask from the counter-based generator, fp32 before rounding
-      const int site = col / p.site_width, cs = col - site * p.site_width;
-      const unsigned key = p.drop_keys[site];
+    if (p.act_out && okv[it]) {  // u = relu(dropout(y)), counter-based mask, applied in fp32 before rounding
       const unsigned long long base = ((unsigned long long)b * p.Ty + ty) * p.site_width + cs;
       Vec<T, EPV> ua;
 #pragma unroll
-      for (int e = 0; e < EPV; ++e) {
-        const bool keep = drop_keep(base + e, key, p.drop_thresh16);
-        ua.v[e] = (T)((keep && o[e] > 0.f) ? o[e] * p.drop_scale : 0.f);
+      for (int e = 0; e < EPV; e += 2) {   // base is even: elements (e, e+1) share one hash
+        const unsigned h = fmix32((unsigned)((base + e) >> 1) * 0x9E3779B1u + key);
+        const bool k0 = (h & 0xFFFFu) >= p.drop_thresh16, k1 = (h >> 16) >= p.drop_thresh16;
+        ua.v[e] = (T)((k0 && o[e] > 0.f) ? o[e] * p.drop_scale : 0.f);
+        ua.v[e + 1] = (T)((k1 && o[e + 1] > 0.f) ? o[e + 1] * p.drop_scale : 0.f);
       }
       *reinterpret_cast<Vec<T, EPV>*>(reinterpret_cast<T*>(p.y_act) + (long long)b * p.ya_bs + (long long)ty * p.ldya + col) = ua;
     }
@@ -228,7 +302,8 @@ static size_t conv_gemm_lds_bytes(const ConvArgs& p, int BN) {
   int rows_in = (BM - 1) * p.stride + (p.taps - 1) * p.dil + 1;
   int pitch_a = std::min(p.Cin, CCH) + EPV;
   size_t a = align_up((size_t)std::max(rows_in * pitch_a, BM * (BN + EPV)) * sizeof(T), 16);
-  return a + (size_t)2 * BN * (KC + EPV) * sizeof(T);
+  const int nsteps = p.taps * ((std::min(p.Cin, CCH) + KC - 1) / KC);
+  return a + (size_t)(nsteps > 1 ? 2 : 1) * BN * (KC + EPV) * sizeof(T);
 }
 
 template <typename T>
@@ -236,26 +311,21 @@ static int launch_conv_gemm(ConvArgs p, hipStream_t stream) {
   constexpr int BM = Tr<T>::BM;
   const int BN = (p.Cout > 64) ? 128 : 64;
   p.tiles_per_batch = (p.Tout + BM - 1) / BM;
-  dim3 grid((unsigned)(p.tiles_per_batch * p.B), (unsigned)((p.Cout + BN - 1) / BN));
+  const int ntiles = p.tiles_per_batch * p.B;
+  dim3 grid((unsigned)(8 * ((ntiles + 7) / 8)), (unsigned)((p.Cout + BN - 1) / BN));
   size_t lds = conv_gemm_lds_bytes<T>(p, BN);
   SMT_CHECK_ARG(lds <= 160 * 1024, "conv_gemm: tile needs %zu B of LDS (taps=%d dil=%d stride=%d Cin=%d)", lds,
                 p.taps, p.dil, p.stride, p.Cin);
+  // two waves per SIMD (512 threads) for the 128-wide bf16 tiles; everything else keeps 256
   if (BN == 128) {
-    static bool attr128 = false;
-    if (!attr128) {
-      (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<T, 128>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024);
-      attr128 = true;
-    }
-    conv_gemm_kernel<T, 128><<<grid, 256, lds, stream>>>(p);
+    constexpr int NT = sizeof(T) == 2 ? 512 : 256;
+    (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<T, 128, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    conv_gemm_kernel<T, 128, NT><<<grid, NT, lds, stream>>>(p);
   } else {
-    static bool attr64 = false;
-    if (!attr64) {
-      (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<T, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024);
-      attr64 = true;
-    }
-    conv_gemm_kernel<T, 64><<<grid, 256, lds, stream>>>(p);
+    (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<T, 64, 256>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    conv_gemm_kernel<T, 64, 256><<<grid, 256, lds, stream>>>(p);
   }
   SMT_CHECK_LAUNCH("conv_gemm");
   return 0;
@@ -306,6 +376,13 @@ extern "C" int smt_conv1d_ntc(const smt_conv_desc* d, smt_stream_t stream_) {
   SMT_CHECK_ARG(d->dtype == SMT_BF16 || d->dtype == SMT_F32, "smt_conv1d_ntc: bad dtype");
   SMT_CHECK_ARG(d->c_in % (2 * epv) == 0, "smt_conv1d_ntc: c_in=%d must be a multiple of %d", d->c_in, 2 * epv);
   SMT_CHECK_ARG(d->c_out % epv == 0, "smt_conv1d_ntc: c_out=%d must be a multiple of %d", d->c_out, epv);
+  {
+    const int cch = d->dtype == SMT_BF16 ? 128 : 64;
+    const int first = d->c_in < cch ? d->c_in : cch;
+    SMT_CHECK_ARG((first & (first - 1)) == 0 && (d->c_in <= cch || d->c_in % cch == 0),
+                  "smt_conv1d_ntc: c_in=%d must be a power of two up to %d or a multiple of it", d->c_in, cch);
+    SMT_CHECK_ARG(!d->act_out || d->site_width % 2 == 0, "smt_conv1d_ntc: site_width must be even");
+  }
   SMT_CHECK_ARG(d->ld_x % epv == 0 && d->ld_y % epv == 0 && (!d->res || d->ld_res % epv == 0) &&
                     (!d->act_grad_src || d->ld_act % epv == 0),
                 "smt_conv1d_ntc: row pitches must keep 16-byte alignment");
@@ -328,6 +405,7 @@ extern "C" int smt_conv1d_ntc(const smt_conv_desc* d, smt_stream_t stream_) {
   for (int i = 0; i < 8; ++i) p.drop_keys[i] = d->drop_keys[i];
   p.site_width = d->site_width; p.drop_thresh16 = d->drop_thresh16; p.drop_scale = d->drop_scale;
   p.tiles_per_batch = 0;
+  { static int dbg = getenv("SMT_CONV_DBG") ? atoi(getenv("SMT_CONV_DBG")) : 0; p.dbg = dbg; }
   if (d->dtype == SMT_BF16) return launch_conv_gemm<__bf16>(p, stream);
   return launch_conv_gemm<float>(p, stream);
 }

@@ -23,13 +23,13 @@ template <typename T> struct Tr;
 template <> struct Tr<__bf16> {
   static constexpr int EPV = 8;      // elements per 16-byte vector
   static constexpr int CCH = 128;    // input channels staged per LDS A chunk
-  static constexpr int KC = 64;      // K per weight chunk
+  static constexpr int KC = 128;     // K per weight chunk (one barrier per tap for 128 input channels)
   static constexpr int BM = 128;
 };
 template <> struct Tr<float> {
   static constexpr int EPV = 4;
   static constexpr int CCH = 64;
-  static constexpr int KC = 32;
+  static constexpr int KC = 64;
   static constexpr int BM = 64;
 };
 

@@ -84,29 +84,43 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 
   for (int t0 = t_begin; t0 < t_end; t0 += R) {
     __syncthreads();
-    // dy tile: rows t0..t0+R, channels co0..co0+64
-    for (int f = tid; f < R * (CB / EPV); f += 256) {
-      const int row = f / (CB / EPV), cv = f % (CB / EPV);
-      const int t = t0 + row;
-      Vec<T, EPV> v;
-#pragma unroll
-      for (int e = 0; e < EPV; ++e) v.v[e] = (T)0.f;
-      const int ty = t * p.out_stride + p.out_offset;
-      if (t < t_end && ty < p.Ty && co0 + cv * EPV < p.Cout)
-        v = *reinterpret_cast<const Vec<T, EPV>*>(dyg + (long long)ty * p.ldy + co0 + cv * EPV);
-      *reinterpret_cast<Vec<T, EPV>*>(lds_dy + row * PITCH + cv * EPV) = v;
-    }
-    // x tile with halo
+    // dy tile (rows t0..t0+R, channels co0..co0+64) and haloed x tile: all loads of a batch are
+    // issued before the first LDS store so that one memory latency covers UB vectors per thread
+    constexpr int VPR = CB / EPV;
+    constexpr int UB = 8;
     const int tin0 = t0 * p.stride - p.pad;
-    for (int f = tid; f < rows_x * (CB / EPV); f += 256) {
-      const int row = f / (CB / EPV), cv = f % (CB / EPV);
-      const int tin = tin0 + row;
-      Vec<T, EPV> v;
+    const int n_dy = R * VPR, n_x = rows_x * VPR;
+    for (int f0 = tid; f0 < n_dy + n_x; f0 += 256 * UB) {
+      Vec<T, EPV> v[UB];
 #pragma unroll
-      for (int e = 0; e < EPV; ++e) v.v[e] = (T)0.f;
-      if (tin >= 0 && tin < len_in && ci0 + cv * EPV < p.Cin)
-        v = *reinterpret_cast<const Vec<T, EPV>*>(xg + (long long)tin * p.ldx + ci0 + cv * EPV);
-      *reinterpret_cast<Vec<T, EPV>*>(lds_x + row * PITCH + cv * EPV) = v;
+      for (int u = 0; u < UB; ++u) {
+        const int f = f0 + 256 * u;
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) v[u].v[e] = (T)0.f;
+        if (f < n_dy) {
+          const int row = f / VPR, cv = f % VPR;
+          const int t = t0 + row;
+          const int ty = t * p.out_stride + p.out_offset;
+          if (t < t_end && ty < p.Ty && co0 + cv * EPV < p.Cout)
+            v[u] = *reinterpret_cast<const Vec<T, EPV>*>(dyg + (long long)ty * p.ldy + co0 + cv * EPV);
+        } else if (f < n_dy + n_x) {
+          const int g = f - n_dy;
+          const int row = g / VPR, cv = g % VPR;
+          const int tin = tin0 + row;
+          if (tin >= 0 && tin < len_in && ci0 + cv * EPV < p.Cin)
+            v[u] = *reinterpret_cast<const Vec<T, EPV>*>(xg + (long long)tin * p.ldx + ci0 + cv * EPV);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int f = f0 + 256 * u;
+        if (f < n_dy) {
+          *reinterpret_cast<Vec<T, EPV>*>(lds_dy + (f / VPR) * PITCH + (f % VPR) * EPV) = v[u];
+        } else if (f < n_dy + n_x) {
+          const int g = f - n_dy;
+          *reinterpret_cast<Vec<T, EPV>*>(lds_x + (g / VPR) * PITCH + (g % VPR) * EPV) = v[u];
+        }
+      }
     }
     __syncthreads();
 

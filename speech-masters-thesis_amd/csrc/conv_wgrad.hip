@@ -29,12 +29,21 @@ struct WgradArgs {
   int ldx, ldy;
   int B, Tin, Tout, Ty, Cin, Cout;
   int taps, stride, dil, pad, out_stride, out_offset;
-  int rows_per_chunk, chunks_per_batch, nblk_ci, with_bias;
+  int rows_per_chunk, chunks_per_batch, nblk_ci, nblk_co, with_bias;
 };
 
+// R = rows per staged tile; CIB = input channels per workgroup (CIB/32 wave columns, 2 wave rows);
+// pitches chosen so that the transposed reads are bank-conflict-free: for ds_read_b64_tr_b16 a
+// 32-lane half touches 4 rows x 2 16-column blocks, which need row pitch == 16 dwords (mod 64).
 template <typename T> struct WTr;
-template <> struct WTr<__bf16> { static constexpr int R = 128; };
-template <> struct WTr<float> { static constexpr int R = 64; };
+template <> struct WTr<__bf16> {
+  static constexpr int R = 128;
+  static constexpr int pitch(int ch) { return ch + 32; }   // 64 ch: 192 B == 48 dwords; 128 ch: 320 B == 16 (mod 64)
+};
+template <> struct WTr<float> {
+  static constexpr int R = 64;
+  static constexpr int pitch(int ch) { return ch + 4; }
+};
 
 // transposed fragment: element e of lane (n = lane&31, hh = lane>>5) = tile[row0 + 8*hh + e][col0 + n]
 __device__ __forceinline__ bf16x8 frag_tr_bf16(const __bf16* tile, int pitch, int row0, int col0, int lane) {
@@ -49,27 +58,36 @@ __device__ __forceinline__ bf16x8 frag_tr_bf16(const __bf16* tile, int pitch, in
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <typename T, int NT>  // NT = number of accumulator planes (taps + optional bias plane)
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
+// NT = accumulator planes (taps + bias plane); CIB = input channels per workgroup; STRIDED = stride > 1
+template <typename T, int NT, int CIB, bool STRIDED>
+__global__ __launch_bounds__(CIB * 4) void conv_wgrad_kernel(WgradArgs p) {
   constexpr int EPV = Tr<T>::EPV;
   constexpr int R = WTr<T>::R;          // rows per staged tile
-  constexpr int CB = 64;                // channels per block side
-  constexpr int PITCH = CB + EPV;
+  constexpr int CB = 64;                // output channels per block
+  constexpr int WNC = CIB / 32;         // wave columns
+  constexpr int NTHR = 128 * WNC;
+  constexpr int PITCH_DY = WTr<T>::pitch(CB), PITCH_X = WTr<T>::pitch(CIB);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WNC, wn = wave % WNC;
   const int r = lane & 31, hh = lane >> 5;
 
-  const int blk = blockIdx.y;
-  const int co0 = (blk / p.nblk_ci) * CB, ci0 = (blk % p.nblk_ci) * CB;
-  const int b = blockIdx.x / p.chunks_per_batch;
-  const int chunk = blockIdx.x % p.chunks_per_batch;
+  // XCD-aware order: the co-blocks of one row chunk run back to back on the same XCD (ids == mod 8),
+  // so the second reader of a chunk's rows hits L2
+  const int nblk = p.nblk_ci * p.nblk_co;
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int blk = q % nblk;
+  const int cgl = (q / nblk) * 8 + xcd;          // global chunk index
+  if (cgl >= p.B * p.chunks_per_batch) return;
+  const int co0 = (blk / p.nblk_ci) * CB, ci0 = (blk % p.nblk_ci) * CIB;
+  const int b = cgl / p.chunks_per_batch;
+  const int chunk = cgl % p.chunks_per_batch;
   const int t_begin = chunk * p.rows_per_chunk;
   const int t_end = min(p.Tout, t_begin + p.rows_per_chunk);
 
   const int rows_x = (R - 1) * p.stride + (p.taps - 1) * p.dil + 1;
-  T* lds_dy = reinterpret_cast<T*>(smem);                 // [R][PITCH]
-  T* lds_x = lds_dy + R * PITCH;                          // [rows_x][PITCH]
+  T* lds_dy = reinterpret_cast<T*>(smem);                 // [R][PITCH_DY]
+  T* lds_x = lds_dy + R * PITCH_DY;                       // [rows_x][PITCH_X]
   const T* xg = reinterpret_cast<const T*>(p.x) + (long long)b * p.x_bs;
   const T* dyg = reinterpret_cast<const T*>(p.dy) + (long long)b * p.dy_bs;
   const int len_in = p.lens_in ? min(p.lens_in[b], p.Tin) : p.Tin;
@@ -86,26 +104,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     __syncthreads();
     // dy tile (rows t0..t0+R, channels co0..co0+64) and haloed x tile: all loads of a batch are
     // issued before the first LDS store so that one memory latency covers UB vectors per thread
-    constexpr int VPR = CB / EPV;
-    constexpr int UB = 8;
+    constexpr int VPR_DY = CB / EPV, VPR_X = CIB / EPV;
+    constexpr int UB = (NT > 6) ? 4 : 8;   // fewer in-flight staging registers when the accumulators are many
     const int tin0 = t0 * p.stride - p.pad;
-    const int n_dy = R * VPR, n_x = rows_x * VPR;
-    for (int f0 = tid; f0 < n_dy + n_x; f0 += 256 * UB) {
+    const int n_dy = R * VPR_DY, n_x = rows_x * VPR_X;
+    for (int f0 = tid; f0 < n_dy + n_x; f0 += NTHR * UB) {
       Vec<T, EPV> v[UB];
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
-        const int f = f0 + 256 * u;
+        const int f = f0 + NTHR * u;
 #pragma unroll
         for (int e = 0; e < EPV; ++e) v[u].v[e] = (T)0.f;
         if (f < n_dy) {
-          const int row = f / VPR, cv = f % VPR;
+          const int row = f / VPR_DY, cv = f % VPR_DY;
           const int t = t0 + row;
           const int ty = t * p.out_stride + p.out_offset;
           if (t < t_end && ty < p.Ty && co0 + cv * EPV < p.Cout)
             v[u] = *reinterpret_cast<const Vec<T, EPV>*>(dyg + (long long)ty * p.ldy + co0 + cv * EPV);
         } else if (f < n_dy + n_x) {
           const int g = f - n_dy;
-          const int row = g / VPR, cv = g % VPR;
+          const int row = g / VPR_X, cv = g % VPR_X;
           const int tin = tin0 + row;
           if (tin >= 0 && tin < len_in && ci0 + cv * EPV < p.Cin)
             v[u] = *reinterpret_cast<const Vec<T, EPV>*>(xg + (long long)tin * p.ldx + ci0 + cv * EPV);
@@ -113,12 +131,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
       }
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
-        const int f = f0 + 256 * u;
+        const int f = f0 + NTHR * u;
         if (f < n_dy) {
-          *reinterpret_cast<Vec<T, EPV>*>(lds_dy + (f / VPR) * PITCH + (f % VPR) * EPV) = v[u];
+          *reinterpret_cast<Vec<T, EPV>*>(lds_dy + (f / VPR_DY) * PITCH_DY + (f % VPR_DY) * EPV) = v[u];
         } else if (f < n_dy + n_x) {
           const int g = f - n_dy;
-          *reinterpret_cast<Vec<T, EPV>*>(lds_x + (g / VPR) * PITCH + (g % VPR) * EPV) = v[u];
+          *reinterpret_cast<Vec<T, EPV>*>(lds_x + (g / VPR_X) * PITCH_X + (g % VPR_X) * EPV) = v[u];
         }
       }
     }
@@ -130,16 +148,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
       bf16x8 ones;
 #pragma unroll
       for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+      // bound the unrolling: hoisting every transposed read of 8 k-steps x NT taps would spill
+#pragma unroll 1
       for (int k0 = 0; k0 < R; k0 += 16) {
-        bf16x8 a = frag_tr_bf16(dyt, PITCH, k0, wm * 32, lane);   // A[co][k] = dy[k][co]
+        bf16x8 a = frag_tr_bf16(dyt, PITCH_DY, k0, wm * 32, lane);   // A[co][k] = dy[k][co]
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           if (j < ntaps) {
             // B[k][ci] = x[(k)*stride + j*dil][ci]   (stride 1 for every transposed read;
             // strided convs read rows k*stride: handled by row index arithmetic below)
             bf16x8 bfrag;
-            if (p.stride == 1) {
-              bfrag = frag_tr_bf16(xt, PITCH, k0 + j * p.dil, wn * 32, lane);
+            if constexpr (!STRIDED) {
+              bfrag = frag_tr_bf16(xt, PITCH_X, k0 + j * p.dil, wn * 32, lane);
             } else {
               // strided rows are not a dense 4-row block: gather element-wise
               typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -147,7 +167,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
                 const short* sp = reinterpret_cast<const short*>(xt) +
-                                  ((k0 + 8 * hh + e) * p.stride + j * p.dil) * PITCH + wn * 32 + r;
+                                  ((k0 + 8 * hh + e) * p.stride + j * p.dil) * PITCH_X + wn * 32 + r;
                 tmp[e] = *sp;
               }
               bfrag = __builtin_bit_cast(bf16x8, tmp);
@@ -161,12 +181,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     } else {
       const float* dyt = reinterpret_cast<const float*>(lds_dy);
       const float* xt = reinterpret_cast<const float*>(lds_x);
+#pragma unroll 2
       for (int k0 = 0; k0 < R; k0 += 2) {
-        const float a = dyt[(k0 + hh) * PITCH + wm * 32 + r];
+        const float a = dyt[(k0 + hh) * PITCH_DY + wm * 32 + r];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           if (j < ntaps) {
-            const float bv = xt[((k0 + hh) * p.stride + j * p.dil) * PITCH + wn * 32 + r];
+            const float bv = xt[((k0 + hh) * p.stride + j * p.dil) * PITCH_X + wn * 32 + r];
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[j], 0, 0, 0);
           } else if (j == ntaps && bias_plane) {
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, 1.0f, acc[j], 0, 0, 0);
@@ -176,8 +197,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     }
   }
   // partial block -> slab[chunk_global][plane][co 64][ci 64] for this (co,ci) block
-  const int planes = ntaps + (p.with_bias ? 1 : 0);
-  float* out = p.slab + ((size_t)blockIdx.x * gridDim.y + blk) * (size_t)planes * CB * CB;
+  const int planes = ntaps + 1;   // slab layout always carries the bias plane (zeros when not requested)
+  float* out = p.slab + ((size_t)cgl * nblk + blk) * (size_t)planes * CB * CIB;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     if (j >= planes) break;
@@ -185,14 +206,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     for (int e = 0; e < 16; ++e) {
       const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;  // co
       const int col = wn * 32 + r;                                 // ci
-      out[((size_t)j * CB + row) * CB + col] = acc[j][e];
+      out[((size_t)j * CB + row) * CIB + col] = acc[j][e];
     }
   }
 }
 
 struct WreduceArgs {
   const float* slab; float* dw; float* db;
-  int n_chunks, nblk, nblk_ci, planes, taps, Cin, Cout, with_bias;
+  int n_chunks, nblk, nblk_ci, planes, taps, Cin, Cout, with_bias, cib;
   long long so, si, sj; int jmap[16];
 };
 
@@ -202,9 +223,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(WreduceArgs p) {
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
   const int ci = (int)(e % p.Cin), co = (int)((e / p.Cin) % p.Cout), plane = (int)(e / ((long long)p.Cin * p.Cout));
-  const int blk = (co / 64) * p.nblk_ci + (ci / 64);
-  const size_t blk_elems = (size_t)p.planes * 64 * 64;
-  const float* src = p.slab + (size_t)blk * blk_elems + ((size_t)plane * 64 + (co % 64)) * 64 + (ci % 64);
+  const int blk = (co / 64) * p.nblk_ci + (ci / p.cib);
+  const size_t blk_elems = (size_t)p.planes * 64 * p.cib;
+  const float* src = p.slab + (size_t)blk * blk_elems + ((size_t)plane * 64 + (co % 64)) * p.cib + (ci % p.cib);
   if (plane == p.taps) {  // bias plane: every ci column holds db[co]; take column 0 of ci-block 0
     if (ci != 0) return;
   }
@@ -214,13 +235,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(WreduceArgs p) {
   else if (p.db) p.db[co] = s;
 }
 
+// input channels per workgroup: 128 (8 waves, two per SIMD) while the accumulator planes fit in the
+// 256-register budget of that occupancy, else 64 (4 waves, one per SIMD, 512 registers)
+static int wgrad_cib(const smt_conv_desc* d) {
+  if (d->dtype != SMT_BF16) return 64;
+  return (d->c_in > 64 && d->stride == 1) ? 128 : 64;
+}
+
 static void wgrad_plan(const smt_conv_desc* d, int* rows_per_chunk, int* chunks_per_batch, int* nblk_co,
                        int* nblk_ci, int* planes) {
+  const int cib = wgrad_cib(d);
   *nblk_co = (d->c_out + 63) / 64;
-  *nblk_ci = (d->c_in + 63) / 64;
+  *nblk_ci = (d->c_in + cib - 1) / cib;
   const int R = d->dtype == SMT_BF16 ? 128 : 64;
   long long total_rows = (long long)d->batch * d->t_out;
-  long long target_wgs = 1024;
+  long long target_wgs = 512;   // two rounds of one workgroup per CU: keeps the partial slabs small
   long long rows = (total_rows * (*nblk_co) * (*nblk_ci) + target_wgs - 1) / target_wgs;
   rows = std::max<long long>(R, (rows + R - 1) / R * R);
   rows = std::min<long long>(rows, ((long long)d->t_out + R - 1) / R * R);
@@ -233,26 +262,42 @@ static void wgrad_plan(const smt_conv_desc* d, int* rows_per_chunk, int* chunks_
 
 using namespace smt;
 
-extern "C" size_t smt_conv1d_wgrad_workspace_bytes(const smt_conv_desc* d) {
+static size_t wgrad_group_ws(const smt_conv_desc* d) {
   int rpc, cpb, nco, nci, planes;
   wgrad_plan(d, &rpc, &cpb, &nco, &nci, &planes);
-  return (size_t)d->batch * cpb * nco * nci * planes * 64 * 64 * sizeof(float);
+  return (size_t)d->batch * cpb * nco * nci * planes * 64 * wgrad_cib(d) * sizeof(float);
 }
 
-template <typename T>
+// Tap groups: more than 5 taps would need more accumulator registers than two waves per SIMD allow,
+// so wide kernels are processed as consecutive groups of <= 5 taps (a group of taps j0.. is the same
+// convolution with padding reduced by j0*dilation).
+constexpr int WG_GROUP = 5;
+static smt_conv_desc wgrad_group_desc(const smt_conv_desc* d, int j0, int n) {
+  smt_conv_desc g = *d;
+  g.taps = n;
+  g.padding = d->padding - j0 * d->dilation;
+  return g;
+}
+
+extern "C" size_t smt_conv1d_wgrad_workspace_bytes(const smt_conv_desc* d) {
+  size_t best = 0;
+  for (int j0 = 0; j0 < d->taps; j0 += WG_GROUP) {
+    smt_conv_desc g = wgrad_group_desc(d, j0, std::min(WG_GROUP, d->taps - j0));
+    best = std::max(best, wgrad_group_ws(&g));
+  }
+  return best;
+}
+
+template <typename T, int CIB, bool STRIDED>
 static int launch_wgrad(const WgradArgs& a, dim3 grid, size_t lds, int planes, hipStream_t stream) {
-#define SMT_WG_CASE(NT)                                                                                       \
-  case NT: {                                                                                                  \
-    static bool attr = false;                                                                                 \
-    if (!attr) {                                                                                              \
-      (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                160 * 1024);                                                                  \
-      attr = true;                                                                                            \
-    }                                                                                                         \
-    conv_wgrad_kernel<T, NT><<<grid, 256, lds, stream>>>(a);                                                  \
-  } break;
+#define SMT_WG_CASE(NT)                                                                                  \
+  case NT:                                                                                               \
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<T, NT, CIB, STRIDED>,                       \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                   \
+    conv_wgrad_kernel<T, NT, CIB, STRIDED><<<grid, CIB * 4, lds, stream>>>(a);                           \
+    break;
   switch (planes) {
-    SMT_WG_CASE(2) SMT_WG_CASE(3) SMT_WG_CASE(4) SMT_WG_CASE(5) SMT_WG_CASE(6) SMT_WG_CASE(8) SMT_WG_CASE(10)
+    SMT_WG_CASE(2) SMT_WG_CASE(3) SMT_WG_CASE(4) SMT_WG_CASE(5) SMT_WG_CASE(6)
     default:
       set_error("conv_wgrad: unsupported tap count %d", planes - 1);
       return 1;
@@ -262,47 +307,68 @@ static int launch_wgrad(const WgradArgs& a, dim3 grid, size_t lds, int planes, h
   return 0;
 }
 
-extern "C" int smt_conv1d_wgrad(const smt_conv_desc* d, float* dweight, int64_t stride_out, int64_t stride_in,
-                                int64_t stride_tap, const int* tap_map, float* dbias, void* workspace,
-                                size_t workspace_bytes, smt_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int wgrad_group(const smt_conv_desc* d, float* dweight, int64_t stride_out, int64_t stride_in,
+                       int64_t stride_tap, const int* tap_map, float* dbias, void* workspace,
+                       size_t workspace_bytes, hipStream_t stream) {
   SMT_CHECK_ARG(d && d->x && d->y && dweight && tap_map && workspace, "smt_conv1d_wgrad: null pointer");
   SMT_CHECK_ARG(d->dtype == SMT_BF16 || d->dtype == SMT_F32, "smt_conv1d_wgrad: bad dtype");
   const int epv = d->dtype == SMT_BF16 ? 8 : 4;
   SMT_CHECK_ARG(d->c_in % epv == 0 && d->c_out % epv == 0 && d->ld_x % epv == 0 && d->ld_y % epv == 0,
                 "smt_conv1d_wgrad: channels / pitches must keep 16-byte alignment");
-  SMT_CHECK_ARG(d->taps >= 1 && d->taps <= WG_MAX_TAPS, "smt_conv1d_wgrad: taps must be in [1, %d]", WG_MAX_TAPS);
-  SMT_CHECK_ARG(workspace_bytes >= smt_conv1d_wgrad_workspace_bytes(d), "smt_conv1d_wgrad: workspace too small");
+  SMT_CHECK_ARG(d->taps >= 1 && d->taps <= WG_GROUP, "smt_conv1d_wgrad: internal tap group too large");
+  SMT_CHECK_ARG(workspace_bytes >= wgrad_group_ws(d), "smt_conv1d_wgrad: workspace too small");
   int rpc, cpb, nco, nci, planes;
   wgrad_plan(d, &rpc, &cpb, &nco, &nci, &planes);
+  const int cib = wgrad_cib(d);
   WgradArgs a;
   a.x = d->x; a.dy = d->y; a.slab = (float*)workspace; a.lens_in = d->lens_in;
   a.x_bs = d->bs_x; a.dy_bs = d->bs_y; a.ldx = d->ld_x; a.ldy = d->ld_y;
   a.B = d->batch; a.Tin = d->t_in; a.Tout = d->t_out; a.Ty = d->t_y; a.Cin = d->c_in; a.Cout = d->c_out;
   a.taps = d->taps; a.stride = d->stride; a.dil = d->dilation; a.pad = d->padding;
   a.out_stride = d->out_stride; a.out_offset = d->out_offset;
-  a.rows_per_chunk = rpc; a.chunks_per_batch = cpb; a.nblk_ci = nci; a.with_bias = 1;
+  a.rows_per_chunk = rpc; a.chunks_per_batch = cpb; a.nblk_ci = nci; a.nblk_co = nco; a.with_bias = dbias ? 1 : 0;
   if (d->batch > 0 && d->t_out > 0) {
-    dim3 grid((unsigned)(d->batch * cpb), (unsigned)(nco * nci));
-    const int R = d->dtype == SMT_BF16 ? 128 : 64;
+    const int n_chunks = d->batch * cpb;
+    dim3 grid((unsigned)(8 * ((n_chunks + 7) / 8) * nco * nci));
+    const bool bf = d->dtype == SMT_BF16;
+    const int R = bf ? 128 : 64;
     const int rows_x = (R - 1) * d->stride + (d->taps - 1) * d->dilation + 1;
-    const size_t esz = d->dtype == SMT_BF16 ? 2 : 4;
-    const size_t lds = (size_t)(R + rows_x) * (64 + epv) * esz;
+    const size_t lds = bf ? ((size_t)R * WTr<__bf16>::pitch(64) + (size_t)rows_x * WTr<__bf16>::pitch(cib)) * 2
+                          : ((size_t)R * WTr<float>::pitch(64) + (size_t)rows_x * WTr<float>::pitch(cib)) * 4;
     SMT_CHECK_ARG(lds <= 160 * 1024, "conv_wgrad: tile needs %zu B of LDS", lds);
-    const int nt = planes;  // accumulator planes = taps + bias plane
-    int rc = d->dtype == SMT_BF16 ? launch_wgrad<__bf16>(a, grid, lds, nt, stream)
-                                  : launch_wgrad<float>(a, grid, lds, nt, stream);
+    int rc;
+    const bool strided = d->stride > 1;
+    if (bf && cib == 128) rc = launch_wgrad<__bf16, 128, false>(a, grid, lds, planes, stream);   // strided convs have <= 5 planes but small c_in
+    else if (bf) rc = strided ? launch_wgrad<__bf16, 64, true>(a, grid, lds, planes, stream)
+                              : launch_wgrad<__bf16, 64, false>(a, grid, lds, planes, stream);
+    else rc = strided ? launch_wgrad<float, 64, true>(a, grid, lds, planes, stream)
+                      : launch_wgrad<float, 64, false>(a, grid, lds, planes, stream);
     if (rc) return rc;
   }
   WreduceArgs r;
   r.slab = (const float*)workspace; r.dw = dweight; r.db = dbias;
   r.n_chunks = d->batch * cpb; r.nblk = nco * nci; r.nblk_ci = nci; r.planes = planes; r.taps = d->taps;
-  r.Cin = d->c_in; r.Cout = d->c_out; r.with_bias = 1;
+  r.Cin = d->c_in; r.Cout = d->c_out; r.with_bias = dbias ? 1 : 0; r.cib = cib;
   r.so = stride_out; r.si = stride_in; r.sj = stride_tap;
   for (int t = 0; t < d->taps; ++t) r.jmap[t] = tap_map[t];
   if (d->batch == 0 || d->t_out == 0) r.n_chunks = 0;
   long long total = (long long)planes * d->c_out * d->c_in;
   conv_wgrad_reduce_kernel<<<(unsigned)((total + 255) / 256), 256, 0, stream>>>(r);
   SMT_CHECK_LAUNCH("conv_wgrad_reduce");
+  return 0;
+}
+
+extern "C" int smt_conv1d_wgrad(const smt_conv_desc* d, float* dweight, int64_t stride_out, int64_t stride_in,
+                                int64_t stride_tap, const int* tap_map, float* dbias, void* workspace,
+                                size_t workspace_bytes, smt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SMT_CHECK_ARG(d && tap_map, "smt_conv1d_wgrad: null pointer");
+  SMT_CHECK_ARG(d->taps >= 1 && d->taps <= 16, "smt_conv1d_wgrad: taps must be in [1, 16]");
+  for (int j0 = 0; j0 < d->taps; j0 += WG_GROUP) {
+    smt_conv_desc g = wgrad_group_desc(d, j0, std::min(WG_GROUP, d->taps - j0));
+    int rc = wgrad_group(&g, dweight, stride_out, stride_in, stride_tap, tap_map + j0, j0 == 0 ? dbias : nullptr,
+                         workspace, workspace_bytes, stream);
+    if (rc) return rc;
+  }
   return 0;
 }

@@ -43,3 +43,16 @@ for (k, dil) in [(1, 1), (3, 1), (9, 27)]:
     ]:
         us = timeit(fn)
         print(f"k={k} dil={dil:2d} {name:32s} {us:9.1f} us  {flops / us / 1e6:7.1f} TF")
+
+print("---- wgrad")
+for (k, dil) in [(1, 1), (3, 1), (5, 3), (9, 27)]:
+    pad = (k - 1) * dil // 2
+    dw = torch.empty(128, 128, k, device="cuda"); db = torch.empty(128, device="cuda")
+    def runw(x, dy):
+        d = C._base_desc(x, dy, None, 128, 128, k, 1, dil, pad, T)
+        C._wgrad(d, dw, 128 * k, k, 1, list(range(k)), db)
+    flops = 2.0 * B * T * 128 * 128 * k
+    us = timeit(lambda: runw(cont_in, res))
+    print(f"wgrad k={k} dil={dil:2d} contig {us:9.1f} us  {flops / us / 1e6:7.1f} TF")
+    us = timeit(lambda: runw(big[:, :, 128:256], big2[:, :, 0:128]))
+    print(f"wgrad k={k} dil={dil:2d} sliced {us:9.1f} us  {flops / us / 1e6:7.1f} TF")

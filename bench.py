@@ -154,11 +154,35 @@ def main():
         kernels = profiler.summary()
         m = cfg.model
         n_rows = args.batch * (args.clip_len // 128)
-        roofline = None
-        for rec in kernels:
-            if rec["name"] == profiler.DOMINANT:
-                roofline = {k: rec[k] for k in ("bound", "achieved", "peak", "unit", "frac")}
-                roofline.update(kernel=rec["name"], launches=rec["launches"], avg_us=rec["avg_us"], traffic=None)
+
+        def group(names, label, bound, dtype):
+            recs = [k for k in kernels if k["name"].split("_k")[0] in names or k["name"] in names]
+            if not recs:
+                return None
+            launches = sum(k["launches"] for k in recs)
+            total_us = sum(k["total_ms"] for k in recs) * 1e3
+            flops = sum(k["alg_flops"] * k["launches"] for k in recs)
+            nbytes = sum(k["alg_bytes"] * k["launches"] for k in recs)
+            if bound == "mfma":
+                achieved, peak, unit = flops / total_us * 1e-6, profiler.PEAK_TFLOPS[dtype], "TFLOP/s"
+            else:
+                achieved, peak, unit = nbytes / total_us * 1e-3, profiler.HBM_PEAK_GBS, "GB/s"
+            return {"kernel": label, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
+                    "frac": achieved / peak, "launches_per_step": launches / args.steps,
+                    "avg_us": total_us / launches, "ms_per_step": total_us * 1e-3 / args.steps,
+                    "alg_flops_per_launch": flops / launches, "alg_bytes_per_launch": nbytes / launches,
+                    "traffic": None}
+
+        dt = "bf16" if m.get("compute_dtype") == "bf16" else "f32"
+        # dominant kernel by time: the implicit-GEMM conv kernel (forward + data-gradient launches)
+        roofline = group({"conv_fwd", "conv_dgrad"}, "smt::conv_gemm_kernel (forward + data gradient launches)", "mfma", dt)
+        extra_rooflines = {
+            "conv_wgrad": group({"conv_wgrad"}, "smt::conv_wgrad_kernel + reduce", "mfma", dt),
+            "vq_forward": group({"vq_forward"}, "smt_vq_forward (prep, score, finalize, rescore, reduce)", "hbm", "f32"),
+            "vq_ema_accumulate": group({"vq_ema_accumulate"}, "smt::vq_ema_accumulate_kernel", "hbm", "f32"),
+            "gate_mix": group({"gate_mix_fwd", "gate_mix_bwd"}, "smt::gate_mix_{fwd,bwd}_kernel", "hbm", dt),
+            "stft_loss": group({"stft_loss_fwd", "stft_loss_bwd"}, "smt::stft_loss_{fwd,bwd}_kernel", "hbm", "f32"),
+        }
         line = {
             "metric": "LJSpeech utterances/sec per VQ-VAE train step",
             "value": args.batch * world * args.steps / elapsed,
@@ -174,6 +198,7 @@ def main():
                        "latent_rows_per_gpu": n_rows, "parallelism": f"dp{world}"},
             "loss": float(loss_dict["loss"].detach()),
             "roofline": roofline,
+            "rooflines_other": extra_rooflines,
             "kernels": kernels,
         }
         note(f"timed region done: {line['value']:.2f} utt/s, {line['ms_per_step']:.1f} ms/step")

@@ -217,22 +217,36 @@ struct WreduceArgs {
   long long so, si, sj; int jmap[16];
 };
 
-// one thread per (plane, co, ci); chunks summed in index order
+// 32 outputs x 8 chunk slices per workgroup: thread (o, s) sums chunks s, s+8, ... in index order, the
+// eight slice sums are then added in slice order -- a fixed summation tree, so the result is
+// bitwise reproducible, with 8x the memory parallelism of one thread per output.
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(WreduceArgs p) {
+  __shared__ float part[8][32];
   const long long total = (long long)p.planes * p.Cout * p.Cin;
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= total) return;
-  const int ci = (int)(e % p.Cin), co = (int)((e / p.Cin) % p.Cout), plane = (int)(e / ((long long)p.Cin * p.Cout));
-  const int blk = (co / 64) * p.nblk_ci + (ci / p.cib);
-  const size_t blk_elems = (size_t)p.planes * 64 * p.cib;
-  const float* src = p.slab + (size_t)blk * blk_elems + ((size_t)plane * 64 + (co % 64)) * p.cib + (ci % p.cib);
-  if (plane == p.taps) {  // bias plane: every ci column holds db[co]; take column 0 of ci-block 0
-    if (ci != 0) return;
-  }
+  const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const long long e = (long long)blockIdx.x * 32 + o;
   float s = 0.f;
-  for (int c = 0; c < p.n_chunks; ++c) s += src[(size_t)c * p.nblk * blk_elems];
-  if (plane < p.taps) p.dw[co * p.so + ci * p.si + p.jmap[plane] * p.sj] = s;
-  else if (p.db) p.db[co] = s;
+  bool live = e < total;
+  int ci = 0, co = 0, plane = 0;
+  if (live) {
+    ci = (int)(e % p.Cin); co = (int)((e / p.Cin) % p.Cout); plane = (int)(e / ((long long)p.Cin * p.Cout));
+    if (plane == p.taps && ci != 0) live = false;  // bias plane: every ci column holds db[co]; take column 0
+  }
+  if (live) {
+    const int blk = (co / 64) * p.nblk_ci + (ci / p.cib);
+    const size_t blk_elems = (size_t)p.planes * 64 * p.cib;
+    const float* src = p.slab + (size_t)blk * blk_elems + ((size_t)plane * 64 + (co % 64)) * p.cib + (ci % p.cib);
+    for (int c = sl; c < p.n_chunks; c += 8) s += src[(size_t)c * p.nblk * blk_elems];
+  }
+  part[sl][o] = s;
+  __syncthreads();
+  if (sl == 0 && live) {
+    float t = part[0][o];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += part[k][o];
+    if (plane < p.taps) p.dw[co * p.so + ci * p.si + p.jmap[plane] * p.sj] = t;
+    else if (p.db) p.db[co] = t;
+  }
 }
 
 // input channels per workgroup: 128 (8 waves, two per SIMD) while the accumulator planes fit in the
@@ -353,7 +367,7 @@ static int wgrad_group(const smt_conv_desc* d, float* dweight, int64_t stride_ou
   for (int t = 0; t < d->taps; ++t) r.jmap[t] = tap_map[t];
   if (d->batch == 0 || d->t_out == 0) r.n_chunks = 0;
   long long total = (long long)planes * d->c_out * d->c_in;
-  conv_wgrad_reduce_kernel<<<(unsigned)((total + 255) / 256), 256, 0, stream>>>(r);
+  conv_wgrad_reduce_kernel<<<(unsigned)((total + 31) / 32), 256, 0, stream>>>(r);
   SMT_CHECK_LAUNCH("conv_wgrad_reduce");
   return 0;
 }

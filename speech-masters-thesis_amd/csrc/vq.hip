@@ -23,16 +23,37 @@ constexpr int VQ_SLICE = 128;         // codes per workgroup (4 chunks of 32)
 constexpr int VQ_CHUNK = 32;
 
 // ---------------------------------------------------------------- prep ------
-// khalf[j] = 0.5 * sum_i k[j][i]^2 (fp32, index order per lane then wave tree);
-// kmax2 = max_j sum_i k[j][i]^2.  One wave per code.
-__global__ __launch_bounds__(256) void vq_prep_kernel(const float* __restrict__ cb, int K, int D,
+// Distances are translation invariant, so the fp32 scoring pass runs on data centred at the codebook
+// mean mu: trained encoders emit rows with a large common offset, and the round-off bound that
+// decides which rows need fp64 re-scoring scales with the NORMS of the operands, not their spread.
+// mu[i] = mean_j k[j][i] (one thread per dimension, index order).
+__global__ __launch_bounds__(1024) void vq_mean_kernel(const float* __restrict__ cb, int K, int D,
+                                                       float* __restrict__ mu) {
+  __shared__ float part[1024];
+  const int parts = 1024 / D;                     // D in {32, 64, 128}
+  const int i = threadIdx.x % D, pt = threadIdx.x / D;
+  float s = 0.f;
+  for (int j = pt; j < K; j += parts) s += cb[(size_t)j * D + i];   // fixed order per part
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (pt == 0) {
+    float t = 0.f;
+    for (int q = 0; q < parts; ++q) t += part[q * D + i];            // parts combined in index order
+    mu[i] = t / (float)K;
+  }
+}
+// kc[j] = k[j] - mu;  khalf[j] = 0.5 * |kc[j]|^2 (fp32, index order per lane then wave tree);
+// kmax2 = max_j |kc[j]|^2.  One wave per code.
+__global__ __launch_bounds__(256) void vq_prep_kernel(const float* __restrict__ cb, const float* __restrict__ mu,
+                                                      int K, int D, float* __restrict__ kc,
                                                       float* __restrict__ khalf, unsigned* __restrict__ kmax2_bits) {
   int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   int lane = threadIdx.x & 63;
   if (wave >= K) return;
   float s = 0.f;
   for (int i = lane; i < D; i += 64) {
-    float v = cb[(size_t)wave * D + i];
+    float v = cb[(size_t)wave * D + i] - mu[i];
+    kc[(size_t)wave * D + i] = v;
     s = fmaf(v, v, s);
   }
   s = wave_sum(s);
@@ -50,6 +71,7 @@ __global__ __launch_bounds__(256) void vq_prep_kernel(const float* __restrict__ 
 // Reduction index split: lane half h = lane >> 5 owns dims [h*D/2, (h+1)*D/2).
 template <int D>
 __global__ __launch_bounds__(256) void vq_score_kernel(const float* __restrict__ x, const float* __restrict__ cb,
+                                                       const float* __restrict__ mu,
                                                        const float* __restrict__ khalf, long long N, int K, int S,
                                                        float* __restrict__ p_best, int* __restrict__ p_idx,
                                                        float* __restrict__ p_second) {
@@ -70,9 +92,10 @@ __global__ __launch_bounds__(256) void vq_score_kernel(const float* __restrict__
   float xb[HD];
   if (row < N) {
     const f32x4* src = reinterpret_cast<const f32x4*>(x + row * D + h * HD);
+    const f32x4* msrc = reinterpret_cast<const f32x4*>(mu + h * HD);
 #pragma unroll
     for (int q = 0; q < HD / 4; ++q) {
-      f32x4 v = src[q];
+      f32x4 v = src[q] - msrc[q];
       xb[4 * q] = v.x; xb[4 * q + 1] = v.y; xb[4 * q + 2] = v.z; xb[4 * q + 3] = v.w;
     }
   } else {
@@ -163,6 +186,7 @@ __global__ __launch_bounds__(256) void vq_score_kernel(const float* __restrict__
 // One wave per row: merge slices, test the gap against the round-off bound, and
 // for final rows write idx / min_dist / x_d.  Ambiguous rows go to the queue.
 __global__ __launch_bounds__(256) void vq_finalize_kernel(const float* __restrict__ x, const float* __restrict__ cb,
+                                                          const float* __restrict__ mu,
                                                           const float* __restrict__ row_mask,
                                                           const unsigned* __restrict__ kmax2_bits,
                                                           const float* __restrict__ p_best, const int* __restrict__ p_idx,
@@ -180,7 +204,8 @@ __global__ __launch_bounds__(256) void vq_finalize_kernel(const float* __restric
   for (int u = 0; u < 4; ++u) {
     int i = lane + 64 * u;
     xv[u] = (i < D) ? xr[i] : 0.f;
-    xx = fmaf(xv[u], xv[u], xx);
+    const float xc = (i < D) ? xv[u] - mu[i] : 0.f;   // centred, as the scoring pass saw it
+    xx = fmaf(xc, xc, xx);
   }
   xx = wave_sum(xx);
   float best = -INFINITY, second = -INFINITY;
@@ -194,10 +219,14 @@ __global__ __launch_bounds__(256) void vq_finalize_kernel(const float* __restric
       second = fmaxf(second, b);
     }
   }
-  // |acc_fp32 - acc_exact| <= gamma_(D+1) * (sum|x_i k_i| + |k|^2/2) + (fp32 error of khalf)
-  //                         <= 1.05*(D+2)*2^-24 * (|x| |k|max + |k|max^2)          (Cauchy-Schwarz)
+  // On centred operands x~ = x - mu, k~ = k - mu (norms below are the centred ones):
+  //   |acc_fp32 - acc_exact(x~,k~)| <= gamma_(D+1) * (sum|x~_i k~_i| + |k~|^2/2) + (fp32 error of khalf)
+  //                                 <= 1.05*(D+2)*2^-24 * (|x~| |k~|max + |k~|max^2)      (Cauchy-Schwarz)
+  //   rounding x - mu and k - mu perturbs the distance by <= 2*2^-24 (|x~| + |k~|max)^2, i.e. half of
+  //   that in acc units.
   const float kmax2 = __uint_as_float(*kmax2_bits);
-  const float err = 1.05f * (float)(D + 2) * 5.9604645e-8f * (sqrtf(xx * kmax2) + kmax2);
+  const float xk = sqrtf(xx * kmax2);
+  const float err = 5.9604645e-8f * (1.05f * (float)(D + 2) * (xk + kmax2) + 1.05f * (xx + 2.f * xk + kmax2));
   const bool ambiguous = !((best - second) > 2.0f * err);  // also catches NaN / inf
   if (ambiguous) {
     if (lane == 0) q_rows[atomicAdd(q_count, 1)] = (int)row;
@@ -409,9 +438,10 @@ __global__ __launch_bounds__(1024) void vq_ema_apply_kernel(float* __restrict__ 
 
 struct VqWorkspace {
   float* khalf; unsigned* kmax2; int* q_count; float* p_best; int* p_idx; float* p_second; int* q_rows;
+  float* mu; float* kc;
 };
 
-static size_t vq_layout(long long N, int K, int S, void* base, VqWorkspace* w) {
+static size_t vq_layout(long long N, int K, int D, int S, void* base, VqWorkspace* w) {
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return (char*)base + o; };
   char* p;
@@ -421,6 +451,8 @@ static size_t vq_layout(long long N, int K, int S, void* base, VqWorkspace* w) {
   p = take((size_t)N * S * 4); if (w) w->p_idx = (int*)p;
   p = take((size_t)N * S * 4); if (w) w->p_second = (float*)p;
   p = take((size_t)N * 4);     if (w) w->q_rows = (int*)p;
+  p = take((size_t)D * 4);     if (w) w->mu = (float*)p;
+  p = take((size_t)K * D * 4); if (w) w->kc = (float*)p;
   return off;
 }
 
@@ -429,9 +461,8 @@ static size_t vq_layout(long long N, int K, int S, void* base, VqWorkspace* w) {
 using namespace smt;
 
 extern "C" size_t smt_vq_forward_workspace_bytes(int64_t n_rows, int k_bins, int dim) {
-  (void)dim;
   int S = (k_bins + VQ_SLICE - 1) / VQ_SLICE;
-  return vq_layout(n_rows, k_bins, S, nullptr, nullptr);
+  return vq_layout(n_rows, k_bins, dim, S, nullptr, nullptr);
 }
 
 extern "C" int smt_vq_forward(const float* x, const float* codebook, const float* row_mask, int64_t n_rows, int k_bins,
@@ -443,27 +474,29 @@ extern "C" int smt_vq_forward(const float* x, const float* codebook, const float
   SMT_CHECK_ARG(n_rows < (1ll << 31), "smt_vq_forward: n_rows must be < 2^31");
   SMT_CHECK_ARG(x && codebook && idx && min_dist && sums && workspace, "smt_vq_forward: null pointer");
   const int S = (k_bins + VQ_SLICE - 1) / VQ_SLICE;
-  SMT_CHECK_ARG(workspace_bytes >= vq_layout(n_rows, k_bins, S, nullptr, nullptr), "smt_vq_forward: workspace too small");
+  SMT_CHECK_ARG(workspace_bytes >= vq_layout(n_rows, k_bins, dim, S, nullptr, nullptr), "smt_vq_forward: workspace too small");
   VqWorkspace w;
-  vq_layout(n_rows, k_bins, S, workspace, &w);
+  vq_layout(n_rows, k_bins, dim, S, workspace, &w);
   (void)hipMemsetAsync(w.kmax2, 0, 256, stream);
   if (n_rows == 0) {
     (void)hipMemsetAsync(sums, 0, 16, stream);
     return 0;
   }
-  vq_prep_kernel<<<(k_bins * 64 + 255) / 256, 256, 0, stream>>>(codebook, k_bins, dim, w.khalf, w.kmax2);
+  vq_mean_kernel<<<1, 1024, 0, stream>>>(codebook, k_bins, dim, w.mu);
+  SMT_CHECK_LAUNCH("vq_mean");
+  vq_prep_kernel<<<(k_bins * 64 + 255) / 256, 256, 0, stream>>>(codebook, w.mu, k_bins, dim, w.kc, w.khalf, w.kmax2);
   SMT_CHECK_LAUNCH("vq_prep");
   const long long tiles = (n_rows + VQ_ROWS_PER_WG - 1) / VQ_ROWS_PER_WG;
   const unsigned grid = (unsigned)(tiles * S);
   if (dim == 128)
-    vq_score_kernel<128><<<grid, 256, 0, stream>>>(x, codebook, w.khalf, n_rows, k_bins, S, w.p_best, w.p_idx, w.p_second);
+    vq_score_kernel<128><<<grid, 256, 0, stream>>>(x, w.kc, w.mu, w.khalf, n_rows, k_bins, S, w.p_best, w.p_idx, w.p_second);
   else if (dim == 64)
-    vq_score_kernel<64><<<grid, 256, 0, stream>>>(x, codebook, w.khalf, n_rows, k_bins, S, w.p_best, w.p_idx, w.p_second);
+    vq_score_kernel<64><<<grid, 256, 0, stream>>>(x, w.kc, w.mu, w.khalf, n_rows, k_bins, S, w.p_best, w.p_idx, w.p_second);
   else
-    vq_score_kernel<32><<<grid, 256, 0, stream>>>(x, codebook, w.khalf, n_rows, k_bins, S, w.p_best, w.p_idx, w.p_second);
+    vq_score_kernel<32><<<grid, 256, 0, stream>>>(x, w.kc, w.mu, w.khalf, n_rows, k_bins, S, w.p_best, w.p_idx, w.p_second);
   SMT_CHECK_LAUNCH("vq_score");
   vq_finalize_kernel<<<(unsigned)((n_rows * 64 + 255) / 256), 256, 0, stream>>>(
-      x, codebook, row_mask, w.kmax2, w.p_best, w.p_idx, w.p_second, n_rows, dim, S, (long long*)idx, min_dist, x_d,
+      x, codebook, w.mu, row_mask, w.kmax2, w.p_best, w.p_idx, w.p_second, n_rows, dim, S, (long long*)idx, min_dist, x_d,
       w.q_count, w.q_rows);
   SMT_CHECK_LAUNCH("vq_finalize");
   vq_rescore_kernel<<<256, 256, 0, stream>>>(x, codebook, row_mask, n_rows, k_bins, dim, w.q_count, w.q_rows,

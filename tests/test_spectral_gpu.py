@@ -74,7 +74,7 @@ def test_stft_loss_gradient_is_adjoint_consistent():
     for n_fft, hop, win in [(2048, 240, 1200), (512, 50, 240)]:
         loss = spectral.stft_loss(y, yh, lens, n_fft, hop, win, False)
         gr, = torch.autograd.grad(loss, yh)
-        eps = 1e-2
+        eps = 2e-3   # small enough that the O(eps^2) curvature term is below the 2e-2 tolerance
         lp = spectral.stft_loss(y, (yh + eps * d).detach(), lens, n_fft, hop, win, False)
         lm = spectral.stft_loss(y, (yh - eps * d).detach(), lens, n_fft, hop, win, False)
         fd = (lp - lm).item() / (2 * eps)

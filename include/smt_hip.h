@@ -92,7 +92,9 @@ int smt_vq_ema_apply(float* codebook, float* k_sum, float* k_elem, const float* 
  * SMT_BF16):  dst[tap][o][i] = src[o*stride_out + i*stride_in + tap_map[tap]*stride_tap]. */
 int smt_pack_weight(const float* src, void* dst, int dtype, int n_out, int n_in, int taps,
                     int64_t stride_out, int64_t stride_in, int64_t stride_tap, const int* tap_map,
-                    smt_stream_t stream);
+                    int swizzle, smt_stream_t stream);
+/* swizzle = 1 (bf16, n_in % 128 == 0): LDS-DMA operand layout -- inside every group of 128 input channels the
+ * 8-channel chunk c of row o is stored at chunk position c ^ (o & 15); pass w_swizzled = 1 with it. */
 
 /* One implicit-GEMM convolution over channels-last activations (forward, or a data gradient, which
  * is the same computation on repacked weights):
@@ -121,6 +123,8 @@ typedef struct smt_conv_desc {
   const void* x; const void* w; const float* bias; void* y; void* y_act;
   const void* res; const void* act_grad_src;
   const int* lens_in; const int* lens_out;
+  int w_swizzled;                  /* w was packed with swizzle = 1: enables the LDS-DMA kernel */
+  const void* zero_page;           /* >= 256 zero bytes in device memory (source of out-of-range rows), or NULL */
 } smt_conv_desc;
 int smt_conv1d_ntc(const smt_conv_desc* desc, smt_stream_t stream);
 

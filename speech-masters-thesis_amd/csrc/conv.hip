@@ -296,6 +296,196 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(ConvArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant (bf16, C_in % 128 == 0, C_out % 128 == 0, stride 1): both operands go HBM/L2 -> LDS
+// with global_load_lds_dwordx4 (no VGPR round trip, no ds_write, no staging arithmetic in the loop).
+// A DMA wave-instruction writes 64 x 16 B linearly, so rows cannot be padded; bank conflicts are
+// avoided by an XOR swizzle of the 16-byte chunk index with the row index instead:
+//   activations: applied on the per-lane SOURCE address while staging, undone by the fragment reads;
+//   weights    : pre-swizzled in global memory by smt_pack_weight(swizzle = 1), copied linearly.
+// Rows outside [0, len) are fetched from a zero page.
+constexpr int DMA_BM = 128, DMA_BN = 128, DMA_KC = 128, DMA_NT = 512;
+
+__device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst_wave_base) {
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,
+                                   (void __attribute__((address_space(3)))*)lds_dst_wave_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(DMA_NT) void conv_gemm_dma_kernel(ConvArgs p, const __bf16* __restrict__ zero_page) {
+  typedef __bf16 T;
+  constexpr int EPV = 8, BM = DMA_BM, BN = DMA_BN, KC = DMA_KC, NT = DMA_NT;
+  constexpr int WN = 4, MW = 2;                 // waves 2 (rows) x 4 (cols); wave tile 64 x 32
+  constexpr int ROWB = KC * 2;                  // 256 bytes per LDS row (128 channels)
+  constexpr int PITCH_C = BN + EPV;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, hh = lane >> 5;
+
+  const int ntiles = p.tiles_per_batch * p.B;
+  const int per_xcd = (ntiles + 7) / 8;
+  const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (tile >= ntiles) return;
+  const int b = tile / p.tiles_per_batch;
+  const int t0 = (tile % p.tiles_per_batch) * BM;
+  const int n0 = blockIdx.y * BN;
+
+  const int rows_in = (BM - 1) + (p.taps - 1) * p.dil + 1;
+  const int rows_pad = (rows_in + 3) & ~3;      // DMA granularity: 4 rows (1 KiB) per wave-instruction
+  unsigned char* lds_a = smem;
+  const size_t a_bytes = align_up((size_t)max(rows_pad * ROWB, BM * PITCH_C * 2), 1024);
+  unsigned char* lds_w = smem + a_bytes;        // 2 x [BN rows][256 B]
+  T* lds_c = reinterpret_cast<T*>(smem);
+
+  const T* xg = reinterpret_cast<const T*>(p.x) + (long long)b * p.x_bs;
+  const unsigned char* wg = reinterpret_cast<const unsigned char*>(p.w);
+  const int len_in = p.lens_in ? min(p.lens_in[b], p.Tin) : p.Tin;
+  const int tin0 = t0 - p.pad;
+  const int ncc = p.Cin / KC;
+
+  f32x16 acc[MW];
+#pragma unroll
+  for (int i = 0; i < MW; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  const int lrow = lane >> 4, lch = lane & 15;  // this lane's (row within the 4-row group, chunk) of a DMA instruction
+  auto stage_w = [&](int j, int cc, int buf) {  // 32 KiB = 32 wave-instructions, 4 per wave
+#pragma unroll
+    for (int q = 0; q < (BN / 4) / (NT / 64); ++q) {
+      const int g = wave + (NT / 64) * q;       // 4-row group index 0..31
+      const int co = n0 + 4 * g + lrow;
+      const unsigned char* src = wg + (((size_t)j * p.Cout + co) * ncc + cc) * ROWB + lch * 16;
+      dma16(src, lds_w + (size_t)buf * BN * ROWB + g * 1024);
+    }
+  };
+
+  for (int cc = 0; cc < ncc; ++cc) {
+    __syncthreads();  // previous chunk's readers are done with lds_a / lds_w
+    for (int g = wave; g < rows_pad / 4; g += NT / 64) {
+      const int row = 4 * g + lrow;
+      const int tin = tin0 + row;
+      const bool ok = (row < rows_in) && (tin >= 0) && (tin < len_in);
+      const T* src = ok ? xg + (long long)tin * p.ldx + cc * KC + ((lch ^ (row & 15)) * EPV) : zero_page + lch * EPV;
+      dma16(src, lds_a + g * 1024);
+    }
+    stage_w(0, cc, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int nsteps = p.taps;
+    for (int s = 0; s < nsteps; ++s) {
+      if (s + 1 < nsteps) stage_w(s + 1, cc, (s + 1) & 1);
+      const unsigned char* wb = lds_w + (size_t)(s & 1) * BN * ROWB + (wn * 32 + r) * ROWB;
+      const int bsw = (wn * 32 + r) & 15;
+      const int arow0 = wm * 64 + s * p.dil + r;
+#pragma unroll
+      for (int kk = 0; kk < KC / 16; ++kk) {
+        const int ch = 2 * kk + hh;
+        bf16x8 bv = *reinterpret_cast<const bf16x8*>(wb + ((ch ^ bsw) << 4));
+#pragma unroll
+        for (int i = 0; i < MW; ++i) {
+          const int ar = arow0 + 32 * i;
+          bf16x8 av = *reinterpret_cast<const bf16x8*>(lds_a + ar * ROWB + ((ch ^ (ar & 15)) << 4));
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i], 0, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: identical to conv_gemm_kernel<bf16, 128, 512>
+  const float bval = (p.bias && n0 + wn * 32 + r < p.Cout) ? p.bias[n0 + wn * 32 + r] : 0.f;
+#pragma unroll
+  for (int i = 0; i < MW; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+      lds_c[row * PITCH_C + wn * 32 + r] = (T)(acc[i][e] + bval);
+    }
+  __syncthreads();
+  T* yg = p.y ? reinterpret_cast<T*>(p.y) + (long long)b * p.y_bs : nullptr;
+  const T* rg = p.res ? reinterpret_cast<const T*>(p.res) + (long long)b * p.res_bs : nullptr;
+  const T* hg = p.epi_act ? reinterpret_cast<const T*>(p.gate_h) + (long long)b * p.gh_bs : nullptr;
+  const int len_out = p.lens_out ? p.lens_out[b] : 0x7fffffff;
+  constexpr int CV = BN / EPV, NE = BM * CV / NT;
+  const int cv0 = tid % CV, row0 = tid / CV;
+  const int col = n0 + cv0 * EPV;
+  Vec<T, EPV> rv[NE], uv[NE];
+  bool okv[NE];
+#pragma unroll
+  for (int it = 0; it < NE; ++it) {
+    const int t = t0 + row0 + it * (NT / CV);
+    okv[it] = (t < p.Tout);
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) { rv[it].v[e] = (T)0.f; uv[it].v[e] = (T)0.f; }
+    if (rg && okv[it]) rv[it] = *reinterpret_cast<const Vec<T, EPV>*>(rg + (long long)t * p.ldr + col);
+    if (p.epi_act && okv[it]) uv[it] = *reinterpret_cast<const Vec<T, EPV>*>(hg + (long long)t * p.ldgh + col);
+  }
+  const int site = p.act_out ? col / p.site_width : 0;
+  const unsigned key = p.drop_keys[site & 7];
+  const int cs = col - site * (p.act_out ? p.site_width : 0);
+#pragma unroll
+  for (int it = 0; it < NE; ++it) {
+    const int row = row0 + it * (NT / CV);
+    const int ty = t0 + row;
+    Vec<T, EPV> c = *reinterpret_cast<const Vec<T, EPV>*>(lds_c + row * PITCH_C + cv0 * EPV);
+    float o[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) o[e] = (float)c.v[e];
+    if (p.epi_act) {
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) o[e] = ((float)uv[it].v[e] != 0.f) ? o[e] * p.drop_scale : 0.f;
+    }
+    const float keep_row = (ty >= len_out) ? 0.f : 1.f;
+    if (rg) {
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) o[e] = fmaf(o[e], keep_row, (float)rv[it].v[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) o[e] *= keep_row;
+    }
+    if (yg && okv[it]) {
+      Vec<T, EPV> out;
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) out.v[e] = (T)o[e];
+      *reinterpret_cast<Vec<T, EPV>*>(yg + (long long)ty * p.ldy + col) = out;
+    }
+    if (p.act_out && okv[it]) {
+      const unsigned long long base = ((unsigned long long)b * p.Ty + ty) * p.site_width + cs;
+      Vec<T, EPV> ua;
+#pragma unroll
+      for (int e = 0; e < EPV; e += 2) {
+        const unsigned h = fmix32((unsigned)((base + e) >> 1) * 0x9E3779B1u + key);
+        const bool k0 = (h & 0xFFFFu) >= p.drop_thresh16, k1 = (h >> 16) >= p.drop_thresh16;
+        ua.v[e] = (T)((k0 && o[e] > 0.f) ? o[e] * p.drop_scale : 0.f);
+        ua.v[e + 1] = (T)((k1 && o[e + 1] > 0.f) ? o[e + 1] * p.drop_scale : 0.f);
+      }
+      *reinterpret_cast<Vec<T, EPV>*>(reinterpret_cast<T*>(p.y_act) + (long long)b * p.ya_bs + (long long)ty * p.ldya + col) = ua;
+    }
+  }
+}
+
+static bool conv_dma_eligible(const smt_conv_desc* d) {
+  return d->dtype == SMT_BF16 && d->w_swizzled && d->c_in % 128 == 0 && d->c_out % 128 == 0 && d->stride == 1 &&
+         d->out_stride == 1 && d->out_offset == 0 && d->t_y == d->t_out && d->zero_page != nullptr;
+}
+
+static int launch_conv_dma(ConvArgs p, const void* zero_page, hipStream_t stream) {
+  p.tiles_per_batch = (p.Tout + DMA_BM - 1) / DMA_BM;
+  const int ntiles = p.tiles_per_batch * p.B;
+  dim3 grid((unsigned)(8 * ((ntiles + 7) / 8)), (unsigned)(p.Cout / DMA_BN));
+  const int rows_in = (DMA_BM - 1) + (p.taps - 1) * p.dil + 1;
+  const int rows_pad = (rows_in + 3) & ~3;
+  const size_t a_bytes = align_up((size_t)std::max(rows_pad * 256, DMA_BM * (DMA_BN + 8) * 2), 1024);
+  const size_t lds = a_bytes + (size_t)2 * DMA_BN * 256;
+  SMT_CHECK_ARG(lds <= 160 * 1024, "conv_gemm_dma: tile needs %zu B of LDS", lds);
+  (void)hipFuncSetAttribute((const void*)conv_gemm_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  conv_gemm_dma_kernel<<<grid, DMA_NT, lds, stream>>>(p, (const __bf16*)zero_page);
+  SMT_CHECK_LAUNCH("conv_gemm_dma");
+  return 0;
+}
+
 template <typename T>
 static size_t conv_gemm_lds_bytes(const ConvArgs& p, int BN) {
   constexpr int EPV = Tr<T>::EPV, CCH = Tr<T>::CCH, KC = Tr<T>::KC, BM = Tr<T>::BM;
@@ -333,7 +523,7 @@ static int launch_conv_gemm(ConvArgs p, hipStream_t stream) {
 
 // ---- weight repacking: dst[tap][o][i] (act dtype) = src[o*so + i*si + jmap[tap]*sj] (fp32) ------------
 struct PackArgs {
-  const float* src; void* dst; int O, I, taps; long long so, si, sj; int jmap[16];
+  const float* src; void* dst; int O, I, taps; long long so, si, sj; int jmap[16]; int swizzle;
 };
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weight_kernel(PackArgs p) {
@@ -342,7 +532,12 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(PackArgs p) {
     int i = (int)(e % p.I);
     int o = (int)((e / p.I) % p.O);
     int tap = (int)(e / ((long long)p.I * p.O));
-    reinterpret_cast<T*>(p.dst)[e] = (T)p.src[o * p.so + i * p.si + p.jmap[tap] * p.sj];
+    long long dst = e;
+    if (p.swizzle) {  // LDS-DMA layout: within every 128-channel group the 8-channel chunk index is XORed with (o & 15)
+      const int chunk = (i >> 3) & 15;
+      dst = e - ((long long)chunk << 3) + ((long long)(chunk ^ (o & 15)) << 3);
+    }
+    reinterpret_cast<T*>(p.dst)[dst] = (T)p.src[o * p.so + i * p.si + p.jmap[tap] * p.sj];
   }
 }
 
@@ -352,7 +547,7 @@ using namespace smt;
 
 extern "C" int smt_pack_weight(const float* src, void* dst, int dtype, int n_out, int n_in, int taps,
                                int64_t stride_out, int64_t stride_in, int64_t stride_tap, const int* tap_map,
-                               smt_stream_t stream_) {
+                               int swizzle, smt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SMT_CHECK_ARG(src && dst && tap_map, "smt_pack_weight: null pointer");
   SMT_CHECK_ARG(taps >= 1 && taps <= 16, "smt_pack_weight: taps must be in [1, 16]");
@@ -360,6 +555,8 @@ extern "C" int smt_pack_weight(const float* src, void* dst, int dtype, int n_out
   p.src = src; p.dst = dst; p.O = n_out; p.I = n_in; p.taps = taps;
   p.so = stride_out; p.si = stride_in; p.sj = stride_tap;
   for (int t = 0; t < taps; ++t) p.jmap[t] = tap_map[t];
+  SMT_CHECK_ARG(!swizzle || (n_in % 128 == 0 && dtype == SMT_BF16), "smt_pack_weight: swizzle needs bf16 and n_in %% 128 == 0");
+  p.swizzle = swizzle;
   long long total = (long long)taps * n_out * n_in;
   unsigned grid = (unsigned)std::min<long long>(1024, (total + 255) / 256);
   if (dtype == SMT_BF16) pack_weight_kernel<__bf16><<<grid, 256, 0, stream>>>(p);
@@ -406,6 +603,11 @@ extern "C" int smt_conv1d_ntc(const smt_conv_desc* d, smt_stream_t stream_) {
   p.site_width = d->site_width; p.drop_thresh16 = d->drop_thresh16; p.drop_scale = d->drop_scale;
   p.tiles_per_batch = 0;
   { static int dbg = getenv("SMT_CONV_DBG") ? atoi(getenv("SMT_CONV_DBG")) : 0; p.dbg = dbg; }
+  if (conv_dma_eligible(d)) {
+    const int rows_in = 127 + (d->taps - 1) * d->dilation + 1;
+    if (((rows_in + 3) & ~3) * 256 + 2 * 128 * 256 <= 160 * 1024) return launch_conv_dma(p, d->zero_page, stream);
+  }
+  SMT_CHECK_ARG(!d->w_swizzled, "smt_conv1d_ntc: swizzled weights need the LDS-DMA path (bf16, stride 1, channels %% 128)");
   if (d->dtype == SMT_BF16) return launch_conv_gemm<__bf16>(p, stream);
   return launch_conv_gemm<float>(p, stream);
 }

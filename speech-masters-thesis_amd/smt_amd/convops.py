@@ -37,7 +37,8 @@ class ConvDesc(ctypes.Structure):
                 ("bs_x", ctypes.c_int64), ("bs_y", ctypes.c_int64), ("bs_res", ctypes.c_int64),
                 ("bs_act", ctypes.c_int64), ("bs_yact", ctypes.c_int64), ("x", ctypes.c_void_p), ("w", ctypes.c_void_p),
                 ("bias", ctypes.c_void_p), ("y", ctypes.c_void_p), ("y_act", ctypes.c_void_p), ("res", ctypes.c_void_p),
-                ("act_grad_src", ctypes.c_void_p), ("lens_in", ctypes.c_void_p), ("lens_out", ctypes.c_void_p)]
+                ("act_grad_src", ctypes.c_void_p), ("lens_in", ctypes.c_void_p), ("lens_out", ctypes.c_void_p),
+                ("w_swizzled", ctypes.c_int), ("zero_page", ctypes.c_void_p)]
 
 
 @dataclass
@@ -86,13 +87,34 @@ def _i32(lens):
     return lens if lens.dtype == torch.int32 else lens.to(torch.int32)
 
 
-def _pack(weight, dtype, n_out, n_in, s_out, s_in, s_tap, tap_map):
+def _pack(weight, dtype, n_out, n_in, s_out, s_in, s_tap, tap_map, swizzle=False):
     taps = len(tap_map)
     dst = torch.empty(taps, n_out, n_in, dtype=dtype, device=weight.device)
     arr = (ctypes.c_int * taps)(*tap_map)
     N.check(N.lib().smt_pack_weight(_p(weight), _p(dst), _DT[dtype], n_out, n_in, taps, s_out, s_in, s_tap, arr,
-                                    N.stream_ptr()), "smt_pack_weight")
+                                    int(swizzle), N.stream_ptr()), "smt_pack_weight")
     return dst
+
+
+_zero_pages = {}
+
+
+def _zero_page(device):
+    key = (device.type, device.index)
+    if key not in _zero_pages:
+        _zero_pages[key] = torch.zeros(4096, dtype=torch.uint8, device=device)
+    return _zero_pages[key]
+
+
+def _dma_ok(dtype, c_in, c_out):
+    """LDS-DMA kernel: bf16, both channel counts multiples of 128, stride 1 (include/smt_hip.h)."""
+    return dtype == torch.bfloat16 and c_in % 128 == 0 and c_out % 128 == 0
+
+
+def _use_dma(d, w_packed):
+    d.w = _p(w_packed)
+    d.w_swizzled = 1
+    d.zero_page = _p(_zero_page(w_packed.device))
 
 
 def _tag(desc):
@@ -178,15 +200,15 @@ def _dgrad_stride1(dy, weight_packed_bwd, dx, k, dilation, padding):
     return d
 
 
-def _pack_fwd(weight, dtype):
+def _pack_fwd(weight, dtype, swizzle=False):
     c_out, c_in, k = weight.shape
-    return _pack(weight, dtype, c_out, c_in, c_in * k, k, 1, list(range(k)))
+    return _pack(weight, dtype, c_out, c_in, c_in * k, k, 1, list(range(k)), swizzle)
 
 
-def _pack_bwd(weight, dtype):
+def _pack_bwd(weight, dtype, swizzle=False):
     """[tap][ci][co] with flipped taps: the data gradient of a stride-1 conv is a conv with these."""
     c_out, c_in, k = weight.shape
-    return _pack(weight, dtype, c_in, c_out, k, c_in * k, 1, [k - 1 - j for j in range(k)])
+    return _pack(weight, dtype, c_in, c_out, k, c_in * k, 1, [k - 1 - j for j in range(k)], swizzle)
 
 
 class _Conv1d(torch.autograd.Function):
@@ -456,13 +478,21 @@ class _GatedHiFi(torch.autograd.Function):
             sl = slice(d * c2, (d + 1) * c2)
             u1_d, u2_d = u1[:, :, sl], u2[:, :, sl]
             d2 = _base_desc(u1_d, None, None, c2, c2, k, 1, dil, pad, t, t_y=t)
-            d2.w, d2.bias = _p(_pack_fwd(br[d][2], dt)), _p(br[d][3])
+            dma = _dma_ok(dt, c2, c2)
+            wp2 = _pack_fwd(br[d][2], dt, dma)
+            d2.w, d2.bias = _p(wp2), _p(br[d][3])
+            if dma:
+                _use_dma(d2, wp2)
             _set_act_out(d2, u2_d, [specs[d][1][0]], thresh, scale, c2)
             _launch(d2, "conv_fwd", _conv_flops(d2), _conv_bytes(d2, x.element_size()))
         for d in range(depth):
             sl = slice(d * c2, (d + 1) * c2)
             d3 = _base_desc(u2[:, :, sl], z[:, :, sl], None, c2, c2, 1, 1, 1, 0, t)
-            d3.w, d3.bias = _p(_pack_fwd(br[d][4], dt)), _p(br[d][5])
+            dma = _dma_ok(dt, c2, c2)
+            wp3 = _pack_fwd(br[d][4], dt, dma)
+            d3.w, d3.bias = _p(wp3), _p(br[d][5])
+            if dma:
+                _use_dma(d3, wp3)
             d3.res, d3.bs_res, d3.ld_res = _geom(h1[:, :, sl])
             _launch(d3, "conv_fwd", _conv_flops(d3), _conv_bytes(d3, x.element_size()))
         del h1
@@ -517,14 +547,21 @@ class _GatedHiFi(torch.autograd.Function):
             w1, b1, w2, b2, w3, b3 = br[dd]
             dz_d, u1_d, u2_d = dz[:, :, sl], u1[:, :, sl], u2[:, :, sl]
             # K3: dh2 = (dz_d . W3^T) * act'(u2);  dW3 = u2^T dz_d
-            d = _dgrad_stride1(dz_d, _pack_bwd(w3, dt), dh2, 1, 1, 0)
+            dma = _dma_ok(dt, c2, c2)
+            wb3 = _pack_bwd(w3, dt, dma)
+            d = _dgrad_stride1(dz_d, wb3, dh2, 1, 1, 0)
+            if dma:
+                _use_dma(d, wb3)
             _set_act_grad(d, u2_d, scale)
             _launch(d, "conv_dgrad", _conv_flops(d), _conv_bytes(d, x.element_size()))
             grads[6 * dd + 4], grads[6 * dd + 5] = torch.empty_like(w3), f32(b3.shape)
             _wgrad(_base_desc(u2_d, dz_d, None, c2, c2, 1, 1, 1, 0, t), grads[6 * dd + 4], c2, 1, 1, [0],
                    grads[6 * dd + 5])
             # K2: dh1_d = (dh2 * W2^T) * act'(u1) + dz_d;  dW2 = u1^T dh2
-            d = _dgrad_stride1(dh2, _pack_bwd(w2, dt), dh1[:, :, sl], k, dil, pad)
+            wb2 = _pack_bwd(w2, dt, dma)
+            d = _dgrad_stride1(dh2, wb2, dh1[:, :, sl], k, dil, pad)
+            if dma:
+                _use_dma(d, wb2)
             _set_act_grad(d, u1_d, scale)
             d.res, d.bs_res, d.ld_res = _geom(dz_d)
             _launch(d, "conv_dgrad", _conv_flops(d), _conv_bytes(d, x.element_size()))

@@ -239,3 +239,39 @@ def test_act_out_epilogue_matches_counter_spec():
         ref = torch.relu(y[:, :, s * sw:(s + 1) * sw]) * keep / (1.0 - p)
         assert torch.allclose(u[:, :, s * sw:(s + 1) * sw], ref, atol=1e-6, rtol=1e-6)
         assert abs(keep.float().mean().item() - 0.9) < 0.01
+
+
+@pytest.mark.parametrize("k,dil", [(1, 1), (3, 1), (5, 3), (7, 9), (9, 27)])
+def test_lds_dma_conv_kernel_matches_generic_kernel(k, dil):
+    """The LDS-DMA variant (bf16, C % 128 == 0, XOR-swizzled operands) against the register-staged generic
+    kernel on the same inputs: same MFMA, same k order -> bit-identical outputs; ragged lens, residual,
+    activation-derivative epilogue and the activated second output included."""
+    from smt_amd import convops as C
+    g = torch.Generator(device="cuda").manual_seed(k)
+    b, t, c = 3, 700, 128
+    big = torch.randn(b, t, 512, device="cuda", generator=g).to(torch.bfloat16)
+    x = big[:, :, 128:256]                                   # channel slice: row pitch 512
+    w = torch.randn(c, c, k, device="cuda", generator=g) / (c * k) ** 0.5
+    bias = torch.randn(c, device="cuda", generator=g)
+    res = torch.randn(b, t, c, device="cuda", generator=g).to(torch.bfloat16)
+    u_src = torch.relu(torch.randn(b, t, c, device="cuda", generator=g)).to(torch.bfloat16)
+    lens = torch.tensor([t, 333, 1], device="cuda", dtype=torch.int32)
+    pad = (k - 1) * dil // 2
+    outs = []
+    for dma in (False, True):
+        y = torch.zeros(b, t, c, device="cuda", dtype=torch.bfloat16)
+        u = torch.zeros_like(y)
+        wp = C._pack_fwd(w, torch.bfloat16, dma)
+        d = C._base_desc(x, y, lens, c, c, k, 1, dil, pad, t)
+        d.w, d.bias = C._p(wp), C._p(bias)
+        if dma:
+            C._use_dma(d, wp)
+        d.res, d.bs_res, d.ld_res = C._geom(res)
+        d.lens_out = C._p(lens)
+        C._set_act_grad(d, u_src, 1.111)
+        C._set_act_out(d, u, [C.dropout_key(3, 5)], 6554, 1.0 / 0.9, c)
+        C._launch(d, "t")
+        torch.cuda.synchronize()
+        outs.append((y, u))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][0].float().abs().sum() > 0

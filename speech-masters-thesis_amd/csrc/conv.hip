@@ -349,6 +349,24 @@ __global__ __launch_bounds__(DMA_NT) void conv_gemm_dma_kernel(ConvArgs p, const
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
+  // epilogue operands (residual, activation source) are requested NOW so that they arrive under the GEMM
+  constexpr int CV = BN / EPV, NE = BM * CV / NT;
+  const int cv0 = tid % CV, row0 = tid / CV;
+  const int col = n0 + cv0 * EPV;
+  const T* rg = p.res ? reinterpret_cast<const T*>(p.res) + (long long)b * p.res_bs : nullptr;
+  const T* hg = p.epi_act ? reinterpret_cast<const T*>(p.gate_h) + (long long)b * p.gh_bs : nullptr;
+  Vec<T, EPV> rv[NE], uv[NE];
+  bool okv[NE];
+#pragma unroll
+  for (int it = 0; it < NE; ++it) {
+    const int t = t0 + row0 + it * (NT / CV);
+    okv[it] = (t < p.Tout);
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) { rv[it].v[e] = (T)0.f; uv[it].v[e] = (T)0.f; }
+    if (rg && okv[it]) rv[it] = *reinterpret_cast<const Vec<T, EPV>*>(rg + (long long)t * p.ldr + col);
+    if (p.epi_act && okv[it]) uv[it] = *reinterpret_cast<const Vec<T, EPV>*>(hg + (long long)t * p.ldgh + col);
+  }
+
   const int lrow = lane >> 4, lch = lane & 15;  // this lane's (row within the 4-row group, chunk) of a DMA instruction
   auto stage_w = [&](int j, int cc, int buf) {  // 32 KiB = 32 wave-instructions, 4 per wave
 #pragma unroll
@@ -405,23 +423,7 @@ __global__ __launch_bounds__(DMA_NT) void conv_gemm_dma_kernel(ConvArgs p, const
     }
   __syncthreads();
   T* yg = p.y ? reinterpret_cast<T*>(p.y) + (long long)b * p.y_bs : nullptr;
-  const T* rg = p.res ? reinterpret_cast<const T*>(p.res) + (long long)b * p.res_bs : nullptr;
-  const T* hg = p.epi_act ? reinterpret_cast<const T*>(p.gate_h) + (long long)b * p.gh_bs : nullptr;
   const int len_out = p.lens_out ? p.lens_out[b] : 0x7fffffff;
-  constexpr int CV = BN / EPV, NE = BM * CV / NT;
-  const int cv0 = tid % CV, row0 = tid / CV;
-  const int col = n0 + cv0 * EPV;
-  Vec<T, EPV> rv[NE], uv[NE];
-  bool okv[NE];
-#pragma unroll
-  for (int it = 0; it < NE; ++it) {
-    const int t = t0 + row0 + it * (NT / CV);
-    okv[it] = (t < p.Tout);
-#pragma unroll
-    for (int e = 0; e < EPV; ++e) { rv[it].v[e] = (T)0.f; uv[it].v[e] = (T)0.f; }
-    if (rg && okv[it]) rv[it] = *reinterpret_cast<const Vec<T, EPV>*>(rg + (long long)t * p.ldr + col);
-    if (p.epi_act && okv[it]) uv[it] = *reinterpret_cast<const Vec<T, EPV>*>(hg + (long long)t * p.ldgh + col);
-  }
   const int site = p.act_out ? col / p.site_width : 0;
   const unsigned key = p.drop_keys[site & 7];
   const int cs = col - site * (p.act_out ? p.site_width : 0);
@@ -466,6 +468,172 @@ __global__ __launch_bounds__(DMA_NT) void conv_gemm_dma_kernel(ConvArgs p, const
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Persistent 1x1 variant (bf16, C_in == 128, C_out % 128 == 0): an HBM-bound layer.  Each workgroup keeps
+// its 128 x 128 weight block in REGISTERS (32 VGPRs per lane) for its whole run of row tiles, streams the
+// activation tiles through an LDS double buffer by LDS-DMA (tile i+1 is in flight while tile i is
+// multiplied, staged and stored) and requests the epilogue operands of a tile before its MFMAs.
+constexpr int P1_BUF = 35 * 1024;   // 128 rows x 256 B operand tile, reused as the 128 x 272 B output staging tile
+
+__global__ __launch_bounds__(DMA_NT) void conv1x1_dma_kernel(ConvArgs p, const __bf16* __restrict__ zero_page,
+                                                             int tiles_per_wg) {
+  typedef __bf16 T;
+  constexpr int EPV = 8, BM = DMA_BM, BN = DMA_BN, KC = DMA_KC, NT = DMA_NT;
+  constexpr int WN = 4, MW = 2, ROWB = KC * 2, PITCH_C = BN + EPV;
+  constexpr int CV = BN / EPV, NE = BM * CV / NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, hh = lane >> 5;
+  const int lrow = lane >> 4, lch = lane & 15;
+  const int n0 = blockIdx.y * BN;
+
+  // contiguous run of tiles per workgroup; runs of workgroups b, b+8, ... (one XCD) are adjacent
+  const int ntiles = p.tiles_per_batch * p.B;
+  const int nwg = gridDim.x;
+  const int wg = (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3);
+  const int tile_begin = wg * tiles_per_wg;
+  const int tile_end = min(ntiles, tile_begin + tiles_per_wg);
+  if (tile_begin >= tile_end) return;
+
+  // weight fragments -> registers (weights are packed swizzled: chunk c of row co sits at c ^ (co & 15))
+  bf16x8 wfrag[KC / 16];
+  {
+    const int co = n0 + wn * 32 + r;
+    const unsigned char* wrow = reinterpret_cast<const unsigned char*>(p.w) + (size_t)co * ROWB;
+#pragma unroll
+    for (int kk = 0; kk < KC / 16; ++kk) wfrag[kk] = *reinterpret_cast<const bf16x8*>(wrow + (((2 * kk + hh) ^ (co & 15)) << 4));
+  }
+  const float bval = p.bias ? p.bias[n0 + wn * 32 + r] : 0.f;
+  const int cv0 = tid % CV, row0 = tid / CV;
+  const int col = n0 + cv0 * EPV;
+  const int site = p.act_out ? col / p.site_width : 0;
+  const unsigned key = p.drop_keys[site & 7];
+  const int cs = col - site * (p.act_out ? p.site_width : 0);
+
+  auto stage_a = [&](int tile, int buf) {
+    const int b = tile / p.tiles_per_batch;
+    const int t0 = (tile % p.tiles_per_batch) * BM;
+    const T* xg = reinterpret_cast<const T*>(p.x) + (long long)b * p.x_bs;
+    const int len_in = p.lens_in ? min(p.lens_in[b], p.Tin) : p.Tin;
+#pragma unroll
+    for (int q = 0; q < (BM / 4) / (NT / 64); ++q) {
+      const int g = wave + (NT / 64) * q;
+      const int row = 4 * g + lrow;
+      const int tin = t0 + row;
+      const T* src = (tin < len_in) ? xg + (long long)tin * p.ldx + ((lch ^ (row & 15)) * EPV) : zero_page + lch * EPV;
+      dma16(src, smem + (size_t)buf * P1_BUF + g * 1024);
+    }
+  };
+
+  stage_a(tile_begin, 0);
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    const int buf = (tile - tile_begin) & 1;
+    const int b = tile / p.tiles_per_batch;
+    const int t0 = (tile % p.tiles_per_batch) * BM;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's operand has landed (and older stores retired)
+    __syncthreads();                                    // ... for every wave; the other buffer is free again
+    if (tile + 1 < tile_end) stage_a(tile + 1, buf ^ 1);
+    // epilogue operands of THIS tile: requested before the MFMAs
+    const T* rg = p.res ? reinterpret_cast<const T*>(p.res) + (long long)b * p.res_bs : nullptr;
+    const T* hg = p.epi_act ? reinterpret_cast<const T*>(p.gate_h) + (long long)b * p.gh_bs : nullptr;
+    Vec<T, EPV> rv[NE], uv[NE];
+    bool okv[NE];
+#pragma unroll
+    for (int it = 0; it < NE; ++it) {
+      const int t = t0 + row0 + it * (NT / CV);
+      okv[it] = (t < p.Tout);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) { rv[it].v[e] = (T)0.f; uv[it].v[e] = (T)0.f; }
+      if (rg && okv[it]) rv[it] = *reinterpret_cast<const Vec<T, EPV>*>(rg + (long long)t * p.ldr + col);
+      if (p.epi_act && okv[it]) uv[it] = *reinterpret_cast<const Vec<T, EPV>*>(hg + (long long)t * p.ldgh + col);
+    }
+    const unsigned char* lds_a = smem + (size_t)buf * P1_BUF;
+    f32x16 acc[MW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KC / 16; ++kk) {
+      const int ch = 2 * kk + hh;
+#pragma unroll
+      for (int i = 0; i < MW; ++i) {
+        const int ar = wm * 64 + 32 * i + r;
+        bf16x8 av = *reinterpret_cast<const bf16x8*>(lds_a + ar * ROWB + ((ch ^ (ar & 15)) << 4));
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, wfrag[kk], acc[i], 0, 0, 0);
+      }
+    }
+    __syncthreads();   // every wave is done reading the operand tile: reuse it as the output staging tile
+    T* lds_c = reinterpret_cast<T*>(smem + (size_t)buf * P1_BUF);
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        lds_c[row * PITCH_C + wn * 32 + r] = (T)(acc[i][e] + bval);
+      }
+    __syncthreads();
+    T* yg = p.y ? reinterpret_cast<T*>(p.y) + (long long)b * p.y_bs : nullptr;
+    const int len_out = p.lens_out ? p.lens_out[b] : 0x7fffffff;
+#pragma unroll
+    for (int it = 0; it < NE; ++it) {
+      const int row = row0 + it * (NT / CV);
+      const int ty = t0 + row;
+      Vec<T, EPV> c = *reinterpret_cast<const Vec<T, EPV>*>(lds_c + row * PITCH_C + cv0 * EPV);
+      float o[EPV];
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) o[e] = (float)c.v[e];
+      if (p.epi_act) {
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) o[e] = ((float)uv[it].v[e] != 0.f) ? o[e] * p.drop_scale : 0.f;
+      }
+      const float keep_row = (ty >= len_out) ? 0.f : 1.f;
+      if (rg) {
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) o[e] = fmaf(o[e], keep_row, (float)rv[it].v[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) o[e] *= keep_row;
+      }
+      if (yg && okv[it]) {
+        Vec<T, EPV> out;
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) out.v[e] = (T)o[e];
+        *reinterpret_cast<Vec<T, EPV>*>(yg + (long long)ty * p.ldy + col) = out;
+      }
+      if (p.act_out && okv[it]) {
+        const unsigned long long base = ((unsigned long long)b * p.Ty + ty) * p.site_width + cs;
+        Vec<T, EPV> ua;
+#pragma unroll
+        for (int e = 0; e < EPV; e += 2) {
+          const unsigned h = fmix32((unsigned)((base + e) >> 1) * 0x9E3779B1u + key);
+          const bool k0 = (h & 0xFFFFu) >= p.drop_thresh16, k1 = (h >> 16) >= p.drop_thresh16;
+          ua.v[e] = (T)((k0 && o[e] > 0.f) ? o[e] * p.drop_scale : 0.f);
+          ua.v[e + 1] = (T)((k1 && o[e + 1] > 0.f) ? o[e + 1] * p.drop_scale : 0.f);
+        }
+        *reinterpret_cast<Vec<T, EPV>*>(reinterpret_cast<T*>(p.y_act) + (long long)b * p.ya_bs + (long long)ty * p.ldya + col) = ua;
+      }
+    }
+    // the next iteration's top barrier orders these LDS reads before the buffer is overwritten by a DMA
+  }
+}
+
+static int launch_conv1x1_dma(ConvArgs p, const void* zero_page, hipStream_t stream) {
+  p.tiles_per_batch = (p.Tout + DMA_BM - 1) / DMA_BM;
+  const int ntiles = p.tiles_per_batch * p.B;
+  // two workgroups per CU (70 KB of LDS each); at least 2 tiles per workgroup so that the pipeline pays
+  int nwg = std::min(512, std::max(8, (ntiles + 1) / 2));
+  nwg = (nwg + 7) / 8 * 8;
+  const int tpw = (ntiles + nwg - 1) / nwg;
+  dim3 grid((unsigned)nwg, (unsigned)(p.Cout / DMA_BN));
+  const size_t lds = 2 * P1_BUF;
+  (void)hipFuncSetAttribute((const void*)conv1x1_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  conv1x1_dma_kernel<<<grid, DMA_NT, lds, stream>>>(p, (const __bf16*)zero_page, tpw);
+  SMT_CHECK_LAUNCH("conv1x1_dma");
+  return 0;
+}
+
 static bool conv_dma_eligible(const smt_conv_desc* d) {
   return d->dtype == SMT_BF16 && d->w_swizzled && d->c_in % 128 == 0 && d->c_out % 128 == 0 && d->stride == 1 &&
          d->out_stride == 1 && d->out_offset == 0 && d->t_y == d->t_out && d->zero_page != nullptr;
@@ -478,7 +646,7 @@ static int launch_conv_dma(ConvArgs p, const void* zero_page, hipStream_t stream
   const int rows_in = (DMA_BM - 1) + (p.taps - 1) * p.dil + 1;
   const int rows_pad = (rows_in + 3) & ~3;
   const size_t a_bytes = align_up((size_t)std::max(rows_pad * 256, DMA_BM * (DMA_BN + 8) * 2), 1024);
-  const size_t lds = a_bytes + (size_t)2 * DMA_BN * 256;
+  const size_t lds = a_bytes + (size_t)(p.taps > 1 ? 2 : 1) * DMA_BN * 256;   // one weight buffer suffices for 1x1
   SMT_CHECK_ARG(lds <= 160 * 1024, "conv_gemm_dma: tile needs %zu B of LDS", lds);
   (void)hipFuncSetAttribute((const void*)conv_gemm_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   conv_gemm_dma_kernel<<<grid, DMA_NT, lds, stream>>>(p, (const __bf16*)zero_page);
@@ -603,6 +771,7 @@ extern "C" int smt_conv1d_ntc(const smt_conv_desc* d, smt_stream_t stream_) {
   p.site_width = d->site_width; p.drop_thresh16 = d->drop_thresh16; p.drop_scale = d->drop_scale;
   p.tiles_per_batch = 0;
   { static int dbg = getenv("SMT_CONV_DBG") ? atoi(getenv("SMT_CONV_DBG")) : 0; p.dbg = dbg; }
+  if (conv_dma_eligible(d) && d->taps == 1 && d->c_in == 128) return launch_conv1x1_dma(p, d->zero_page, stream);
   if (conv_dma_eligible(d)) {
     const int rows_in = 127 + (d->taps - 1) * d->dilation + 1;
     if (((rows_in + 3) & ~3) * 256 + 2 * 128 * 256 <= 160 * 1024) return launch_conv_dma(p, d->zero_page, stream);

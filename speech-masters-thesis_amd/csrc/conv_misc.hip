@@ -51,50 +51,56 @@ __global__ __launch_bounds__(256) void gate_mix_fwd_kernel(const T* __restrict__
   }
 }
 
+// Backward: one lane per (row, branch d, 16-byte channel vector); the softmax statistics over the
+// branches are exchanged with wave shuffles (lanes of one channel vector are `vpr` apart), so a lane
+// holds two operand vectors instead of 2*depth of them: 4x the lanes in flight at a third of the
+// registers -- this is an HBM-latency-bound kernel.  depth must be a power of two <= 8 and
+// depth * (w / EPV) a divisor of 64 (w = 64: 32 lanes per row, two rows per wave).
 template <typename T>
 __global__ __launch_bounds__(256) void gate_mix_bwd_kernel(const T* __restrict__ z, const T* __restrict__ dg,
                                                            T* __restrict__ dz, long long rows, int w, int depth,
                                                            int ldz, int ldg, int lddz) {
   constexpr int EPV = Tr<T>::EPV;
-  const int vpr = w / EPV;
-  const long long total = rows * vpr;
-  for (long long f = (long long)blockIdx.x * 256 + threadIdx.x; f < total; f += (long long)gridDim.x * 256) {
-    const long long row = f / vpr;
-    const int c = (int)(f % vpr) * EPV;
-    float th[GM_MAX_DEPTH][EPV], sm[GM_MAX_DEPTH][EPV];
+  const int vpr = w / EPV;                 // channel vectors per row
+  const int lpr = vpr * depth;             // lanes per row
+  const long long total = rows * lpr;
+  const long long stride = (long long)gridDim.x * 256;
+  const long long n_iter = (total + stride - 1) / stride;     // uniform trip count: shuffles need every lane
+  for (long long it = 0; it < n_iter; ++it) {
+    const long long f = it * stride + (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = f < total;
+    const long long row = live ? f / lpr : 0;
+    const int rem = (int)(f % lpr);
+    const int d = rem / vpr, c = (rem % vpr) * EPV;
+    float th[EPV], sx[EPV], go[EPV];
+    {
+      Vec<T, EPV> a, bb, gv;
 #pragma unroll
-    for (int d = 0; d < GM_MAX_DEPTH; ++d) {
-      if (d < depth) {
-        Vec<T, EPV> a = *reinterpret_cast<const Vec<T, EPV>*>(z + row * ldz + d * 2 * w + c);
-        Vec<T, EPV> b = *reinterpret_cast<const Vec<T, EPV>*>(z + row * ldz + d * 2 * w + w + c);
-#pragma unroll
-        for (int e = 0; e < EPV; ++e) { th[d][e] = tanhf((float)a.v[e]); sm[d][e] = (float)b.v[e]; }
+      for (int e = 0; e < EPV; ++e) { a.v[e] = (T)0.f; bb.v[e] = (T)0.f; gv.v[e] = (T)0.f; }
+      if (live) {
+        a = *reinterpret_cast<const Vec<T, EPV>*>(z + row * ldz + d * 2 * w + c);
+        bb = *reinterpret_cast<const Vec<T, EPV>*>(z + row * ldz + d * 2 * w + w + c);
+        gv = *reinterpret_cast<const Vec<T, EPV>*>(dg + row * ldg + c);
       }
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) { th[e] = tanhf((float)a.v[e]); sx[e] = (float)bb.v[e]; go[e] = (float)gv.v[e]; }
     }
-    Vec<T, EPV> gv = *reinterpret_cast<const Vec<T, EPV>*>(dg + row * ldg + c);
-    Vec<T, EPV> dt[GM_MAX_DEPTH], ds[GM_MAX_DEPTH];
+    Vec<T, EPV> dt, ds;
 #pragma unroll
     for (int e = 0; e < EPV; ++e) {
-      float m = -INFINITY;
-#pragma unroll
-      for (int d = 0; d < GM_MAX_DEPTH; ++d) if (d < depth) m = fmaxf(m, sm[d][e]);
-      float den = 0.f;
-#pragma unroll
-      for (int d = 0; d < GM_MAX_DEPTH; ++d) if (d < depth) { sm[d][e] = __expf(sm[d][e] - m); den += sm[d][e]; }
-      const float go = (float)gv.v[e];
-      float dot = 0.f;
-#pragma unroll
-      for (int d = 0; d < GM_MAX_DEPTH; ++d) if (d < depth) { sm[d][e] /= den; dot += sm[d][e] * th[d][e]; }
-#pragma unroll
-      for (int d = 0; d < GM_MAX_DEPTH; ++d) if (d < depth) {
-        dt[d].v[e] = (T)(go * sm[d][e] * (1.f - th[d][e] * th[d][e]));
-        ds[d].v[e] = (T)(go * sm[d][e] * (th[d][e] - dot));
-      }
+      float m = sx[e];
+      for (int o = vpr; o < lpr; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      const float ex = __expf(sx[e] - m);
+      float den = ex, dot = ex * th[e];
+      for (int o = vpr; o < lpr; o <<= 1) { den += __shfl_xor(den, o, 64); dot += __shfl_xor(dot, o, 64); }
+      const float sm = ex / den;
+      dot /= den;                                  // sum_d softmax_d * tanh_d
+      dt.v[e] = (T)(go[e] * sm * (1.f - th[e] * th[e]));
+      ds.v[e] = (T)(go[e] * sm * (th[e] - dot));
     }
-#pragma unroll
-    for (int d = 0; d < GM_MAX_DEPTH; ++d) if (d < depth) {
-      *reinterpret_cast<Vec<T, EPV>*>(dz + row * lddz + d * 2 * w + c) = dt[d];
-      *reinterpret_cast<Vec<T, EPV>*>(dz + row * lddz + d * 2 * w + w + c) = ds[d];
+    if (live) {
+      *reinterpret_cast<Vec<T, EPV>*>(dz + row * lddz + d * 2 * w + c) = dt;
+      *reinterpret_cast<Vec<T, EPV>*>(dz + row * lddz + d * 2 * w + w + c) = ds;
     }
   }
 }
@@ -299,7 +305,10 @@ extern "C" int smt_gate_mix_bwd(const void* z, const void* dg, void* dz, int dty
   SMT_CHECK_ARG(depth >= 1 && depth <= GM_MAX_DEPTH && width % epv == 0 && ld_z % epv == 0 && ld_g % epv == 0 &&
                     ld_dz % epv == 0, "smt_gate_mix_bwd: bad geometry");
   if (rows == 0) return 0;
-  unsigned grid = ew_grid(rows * (width / epv));
+  const int lpr = (width / epv) * depth;
+  SMT_CHECK_ARG((depth & (depth - 1)) == 0 && lpr <= 64 && 64 % lpr == 0 && ((width / epv) & (width / epv - 1)) == 0,
+                "smt_gate_mix_bwd: depth and width/%d must be powers of two with depth*width/%d <= 64", epv, epv);
+  unsigned grid = ew_grid(rows * lpr);
   if (dtype == SMT_BF16)
     gate_mix_bwd_kernel<__bf16><<<grid, 256, 0, stream>>>((const __bf16*)z, (const __bf16*)dg, (__bf16*)dz, rows, width,
                                                          depth, ld_z, ld_g, ld_dz);

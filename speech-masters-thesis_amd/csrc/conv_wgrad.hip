@@ -211,6 +211,160 @@ __global__ __launch_bounds__(CIB * 4) void conv_wgrad_kernel(WgradArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant (bf16, stride 1, C_in % 128 == 0, C_out % 64 == 0): the dy / x row tiles go
+// HBM/L2 -> LDS with global_load_lds_dwordx4 into a DOUBLE buffer (tile i+1 lands while tile i is
+// multiplied), rows unpadded.  The transposed reads stay conflict-free through an XOR swizzle of the
+// 16-byte chunk index, applied on the source address while staging:
+//   x  rows (256 B): chunk ^ ((row & 3) << 2)        dy rows (128 B): chunk ^ (((row >> 1) & 1) << 2)
+// (a 32-lane half of ds_read_b64_tr_b16 touches 4 rows x 64 B; the swizzles put those on 4 distinct
+// 64-byte slots of the 256-byte bank row).
+__device__ __forceinline__ void wg_dma16(const void* gsrc, void* lds_dst_wave_base) {
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,
+                                   (void __attribute__((address_space(3)))*)lds_dst_wave_base, 16, 0, 0);
+}
+
+// element e of lane (n = lane&31, hh = lane>>5) = tile[row0 + 8*hh + e][col0 + n], rows of ROWB bytes, swizzled
+template <int ROWB, bool IS_X>
+__device__ __forceinline__ bf16x8 frag_tr_swz(const unsigned char* tile, int row0, int col0, int lane) {
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+  const int hh = g >> 1;
+  const int col = col0 + 16 * (g & 1) + 4 * pp;
+  const int chunk = col >> 3, within = (col & 7) * 2;
+  const int ra = row0 + 8 * hh + q, rb = ra + 4;
+  const int fa = IS_X ? ((ra & 3) << 2) : (((ra >> 1) & 1) << 2);
+  const int fb = IS_X ? ((rb & 3) << 2) : (((rb >> 1) & 1) << 2);
+  const unsigned char* a0 = tile + ra * ROWB + ((chunk ^ fa) << 4) + within;
+  const unsigned char* a1 = tile + rb * ROWB + ((chunk ^ fb) << 4) + within;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int NT>
+__global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(WgradArgs p, const __bf16* __restrict__ zero_page) {
+  typedef __bf16 T;
+  constexpr int R = 128, CB = 64, CIB = 128, WNC = 4, NTHR = 512;
+  constexpr int DYB = CB * 2, XB = CIB * 2;         // row bytes
+  constexpr int DY_BYTES = R * DYB;                 // 16 KiB
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WNC, wn = wave % WNC;
+  const int r = lane & 31, hh = lane >> 5;
+
+  const int nblk = p.nblk_ci * p.nblk_co;
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int blk = q % nblk;
+  const int cgl = (q / nblk) * 8 + xcd;
+  if (cgl >= p.B * p.chunks_per_batch) return;
+  const int co0 = (blk / p.nblk_ci) * CB, ci0 = (blk % p.nblk_ci) * CIB;
+  const int b = cgl / p.chunks_per_batch;
+  const int chunk = cgl % p.chunks_per_batch;
+  const int t_begin = chunk * p.rows_per_chunk;
+  const int t_end = min(p.Tout, t_begin + p.rows_per_chunk);
+
+  const int rows_x = (R - 1) + (p.taps - 1) * p.dil + 1;
+  const int rows_x_pad = (rows_x + 3) & ~3;
+  const size_t buf_bytes = (size_t)DY_BYTES + (size_t)rows_x_pad * XB;
+  const T* xg = reinterpret_cast<const T*>(p.x) + (long long)b * p.x_bs;
+  const T* dyg = reinterpret_cast<const T*>(p.dy) + (long long)b * p.dy_bs;
+  const int len_in = p.lens_in ? min(p.lens_in[b], p.Tin) : p.Tin;
+  const bool bias_plane = p.with_bias && (ci0 == 0);
+  const int ntaps = p.taps;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+  auto stage = [&](int t0, int buf) {
+    unsigned char* base = smem + (size_t)buf * buf_bytes;
+    // dy: 128 rows x 8 chunks; one wave-instruction = 8 rows
+    for (int g = wave; g < R / 8; g += NTHR / 64) {
+      const int row = 8 * g + (lane >> 3), pos = lane & 7;
+      const int t = t0 + row;
+      const bool ok = t < t_end;
+      const int ch = pos ^ (((row >> 1) & 1) << 2);
+      const T* src = ok ? dyg + (long long)t * p.ldy + co0 + ch * 8 : zero_page + pos * 8;
+      wg_dma16(src, base + g * 1024);
+    }
+    // x: rows_x_pad rows x 16 chunks; one wave-instruction = 4 rows
+    const int tin0 = t0 - p.pad;
+    for (int g = wave; g < rows_x_pad / 4; g += NTHR / 64) {
+      const int row = 4 * g + (lane >> 4), pos = lane & 15;
+      const int tin = tin0 + row;
+      const bool ok = (row < rows_x) && (tin >= 0) && (tin < len_in);
+      const int ch = pos ^ ((row & 3) << 2);
+      const T* src = ok ? xg + (long long)tin * p.ldx + ci0 + ch * 8 : zero_page + pos * 8;
+      wg_dma16(src, base + DY_BYTES + g * 1024);
+    }
+  };
+
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+  // Per-lane fragment offsets, computed ONCE: the k-step advances rows by 16 (a multiple of 4), so the
+  // swizzle term of a lane depends only on the tap.  Inside the loop every transposed read is then
+  // "base + lane offset + compile-time immediate" -- no address arithmetic between the MFMAs.
+  const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3, thh = tg >> 1;
+  const int coly = wm * 32 + 16 * (tg & 1) + 4 * tp, colx = wn * 32 + 16 * (tg & 1) + 4 * tp;
+  const int lrow = 8 * thh + tq;
+  const int dyoff = lrow * DYB + (((coly >> 3) ^ (((lrow >> 1) & 1) << 2)) << 4) + (coly & 7) * 2;
+  int xoff[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int rj = lrow + j * p.dil;
+    xoff[j] = rj * XB + (((colx >> 3) ^ ((rj & 3) << 2)) << 4) + (colx & 7) * 2;
+  }
+  auto tr2 = [&](const unsigned char* base, int imm, int step4) -> bf16x8 {
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + imm));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + imm + step4));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
+  stage(t_begin, 0);
+  int it = 0;
+  for (int t0 = t_begin; t0 < t_end; t0 += R, ++it) {
+    const int buf = it & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                       // tile `it` has landed for every wave; the other buffer is free
+    if (t0 + R < t_end) stage(t0 + R, buf ^ 1);
+    const unsigned char* dyt = smem + (size_t)buf * buf_bytes + dyoff;
+    const unsigned char* xbase = smem + (size_t)buf * buf_bytes + DY_BYTES;
+#pragma unroll
+    for (int k0 = 0; k0 < R; k0 += 16) {
+      bf16x8 a = tr2(dyt, k0 * DYB, 4 * DYB);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (j < ntaps) {
+          bf16x8 bfrag = tr2(xbase + xoff[j], k0 * XB, 4 * XB);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag, acc[j], 0, 0, 0);
+        } else if (j == ntaps && bias_plane) {
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ones, acc[j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const int planes = ntaps + 1;
+  float* out = p.slab + ((size_t)cgl * nblk + blk) * (size_t)planes * CB * CIB;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    if (j >= planes) break;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+      const int col = wn * 32 + r;
+      out[((size_t)j * CB + row) * CIB + col] = acc[j][e];
+    }
+  }
+}
+
 struct WreduceArgs {
   const float* slab; float* dw; float* db;
   int n_chunks, nblk, nblk_ci, planes, taps, Cin, Cout, with_bias, cib;
@@ -352,7 +506,26 @@ static int wgrad_group(const smt_conv_desc* d, float* dweight, int64_t stride_ou
     SMT_CHECK_ARG(lds <= 160 * 1024, "conv_wgrad: tile needs %zu B of LDS", lds);
     int rc;
     const bool strided = d->stride > 1;
-    if (bf && cib == 128) rc = launch_wgrad<__bf16, 128, false>(a, grid, lds, planes, stream);   // strided convs have <= 5 planes but small c_in
+    const int rows_xp = (rows_x + 3) & ~3;
+    const size_t lds_dma = 2 * ((size_t)128 * 128 + (size_t)rows_xp * 256);
+    const bool dma = bf && cib == 128 && !strided && d->zero_page && d->c_in % 128 == 0 && d->c_out % 64 == 0 &&
+                     d->out_stride == 1 && d->out_offset == 0 && lds_dma <= 160 * 1024;
+    if (dma) {
+#define SMT_WGD_CASE(NT)                                                                                 \
+  case NT:                                                                                               \
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<NT>,                                    \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                   \
+    conv_wgrad_dma_kernel<NT><<<grid, 512, lds_dma, stream>>>(a, (const __bf16*)d->zero_page);           \
+    break;
+      switch (planes) {
+        SMT_WGD_CASE(2) SMT_WGD_CASE(3) SMT_WGD_CASE(4) SMT_WGD_CASE(5) SMT_WGD_CASE(6)
+        default: set_error("conv_wgrad_dma: unsupported tap count"); return 1;
+      }
+#undef SMT_WGD_CASE
+      SMT_CHECK_LAUNCH("conv_wgrad_dma");
+      rc = 0;
+    } else
+    if (bf && cib == 128) rc = launch_wgrad<__bf16, 128, false>(a, grid, lds, planes, stream);
     else if (bf) rc = strided ? launch_wgrad<__bf16, 64, true>(a, grid, lds, planes, stream)
                               : launch_wgrad<__bf16, 64, false>(a, grid, lds, planes, stream);
     else rc = strided ? launch_wgrad<float, 64, true>(a, grid, lds, planes, stream)

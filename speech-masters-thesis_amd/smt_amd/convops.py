@@ -168,6 +168,7 @@ def _base_desc(x, y, lens_in, c_in, c_out, taps, stride, dil, pad, t_out, out_st
 
 def _wgrad(desc, dweight, s_out, s_in, s_tap, tap_map, dbias):
     lib = N.lib()
+    desc.zero_page = _p(_zero_page(dweight.device))     # enables the LDS-DMA variant where eligible
     ws_bytes = lib.smt_conv1d_wgrad_workspace_bytes(ctypes.byref(desc))
     ws = N.workspace.get(ws_bytes, dweight.device)
     arr = (ctypes.c_int * len(tap_map))(*tap_map)

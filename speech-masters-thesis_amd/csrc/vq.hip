@@ -472,7 +472,8 @@ extern "C" int smt_vq_forward(const float* x, const float* codebook, const float
   SMT_CHECK_ARG(dim == 32 || dim == 64 || dim == 128, "smt_vq_forward: dim must be 32, 64 or 128 (got %d)", dim);
   SMT_CHECK_ARG(k_bins >= 1 && n_rows >= 0, "smt_vq_forward: bad sizes n_rows=%lld k_bins=%d", (long long)n_rows, k_bins);
   SMT_CHECK_ARG(n_rows < (1ll << 31), "smt_vq_forward: n_rows must be < 2^31");
-  SMT_CHECK_ARG(x && codebook && idx && min_dist && sums && workspace, "smt_vq_forward: null pointer");
+  SMT_CHECK_ARG(codebook && sums && workspace, "smt_vq_forward: null pointer");
+  SMT_CHECK_ARG(n_rows == 0 || (x && idx && min_dist), "smt_vq_forward: null pointer");
   const int S = (k_bins + VQ_SLICE - 1) / VQ_SLICE;
   SMT_CHECK_ARG(workspace_bytes >= vq_layout(n_rows, k_bins, dim, S, nullptr, nullptr), "smt_vq_forward: workspace too small");
   VqWorkspace w;
@@ -512,8 +513,8 @@ extern "C" int smt_vq_backward(const float* x, const float* codebook, const int6
                                float* dx, smt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SMT_CHECK_ARG(dim % 4 == 0, "smt_vq_backward: dim must be a multiple of 4");
-  SMT_CHECK_ARG(x && codebook && idx && sums && dx, "smt_vq_backward: null pointer");
   if (n_rows == 0) return 0;
+  SMT_CHECK_ARG(x && codebook && idx && sums && dx, "smt_vq_backward: null pointer");
   long long total4 = n_rows * dim / 4;
   unsigned grid = (unsigned)min((long long)2048, (total4 + 255) / 256);
   vq_backward_kernel<<<grid, 256, 0, stream>>>(x, codebook, (const long long*)idx, row_mask, dy, g_commit, sums, n_rows,
@@ -525,7 +526,7 @@ extern "C" int smt_vq_backward(const float* x, const float* codebook, const int6
 extern "C" int smt_vq_ema_accumulate(const float* x, const int64_t* idx, const float* row_mask, int64_t n_rows,
                                      int k_bins, int dim, float* stats, smt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  SMT_CHECK_ARG(x && idx && stats, "smt_vq_ema_accumulate: null pointer");
+  SMT_CHECK_ARG(stats && (n_rows == 0 || (x && idx)), "smt_vq_ema_accumulate: null pointer");
   (void)hipMemsetAsync(stats, 0, ((size_t)k_bins * dim + k_bins) * sizeof(float), stream);
   if (n_rows == 0) return 0;
   unsigned grid = (unsigned)min((long long)4096, (n_rows * 64 + 255) / 256);

@@ -6,8 +6,8 @@
 //
 // Index semantics (oracle/vqvae_oracle.py: vq_argmin_exact): idx = the exact
 // argmin_j ||x - k_j||^2 of the fp32 inputs, lowest j on ties.  Implementation:
-//   1. vq_score   fp32 scores on the matrix cores (v_mfma_f32_32x32x2_f32, exact
-//                 fp32 fma chains), per row best + runner-up per 128-code slice;
+//   1. vq_score   filter scores on the matrix cores (bf16-pair split of the fp32 operands,
+//                 3 x v_mfma_f32_32x32x16_bf16 per k-step), per row best + runner-up per 128-code slice;
 //   2. vq_finalize merges the slices; a row whose best/runner-up gap is inside the
 //                 rigorous fp32 round-off bound is queued, every other row is final;
 //   3. vq_rescore re-scores queued rows over ALL codes in fp64 (index order, no
@@ -42,10 +42,10 @@ __global__ __launch_bounds__(1024) void vq_mean_kernel(const float* __restrict__
     mu[i] = t / (float)K;
   }
 }
-// kc[j] = k[j] - mu;  khalf[j] = 0.5 * |kc[j]|^2 (fp32, index order per lane then wave tree);
+// kc[j] = k[j] - mu, stored as the bf16 pair (kh, kl);  khalf[j] = 0.5 * |kc[j]|^2 (fp32, index order per lane then wave tree);
 // kmax2 = max_j |kc[j]|^2.  One wave per code.
 __global__ __launch_bounds__(256) void vq_prep_kernel(const float* __restrict__ cb, const float* __restrict__ mu,
-                                                      int K, int D, float* __restrict__ kc,
+                                                      int K, int D, __bf16* __restrict__ kh, __bf16* __restrict__ kl,
                                                       float* __restrict__ khalf, unsigned* __restrict__ kmax2_bits) {
   int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   int lane = threadIdx.x & 63;
@@ -53,7 +53,9 @@ __global__ __launch_bounds__(256) void vq_prep_kernel(const float* __restrict__ 
   float s = 0.f;
   for (int i = lane; i < D; i += 64) {
     float v = cb[(size_t)wave * D + i] - mu[i];
-    kc[(size_t)wave * D + i] = v;
+    const __bf16 hi = (__bf16)v;                       // v = hi + lo + eps, |eps| <= 2^-18 |v|
+    kh[(size_t)wave * D + i] = hi;
+    kl[(size_t)wave * D + i] = (__bf16)(v - (float)hi);
     s = fmaf(v, v, s);
   }
   s = wave_sum(s);
@@ -64,22 +66,26 @@ __global__ __launch_bounds__(256) void vq_prep_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------- score -----
-// Workgroup = 4 waves = 128 rows x one 128-code slice.  The codebook is the MFMA
-// A operand (code on the row index i), x the B operand (row on the column index
-// j = lane & 31), so every lane owns ONE x row and sees 16 codes per chunk in its
-// accumulator registers: the running best / runner-up is pure in-lane work.
-// Reduction index split: lane half h = lane >> 5 owns dims [h*D/2, (h+1)*D/2).
+// Workgroup = 4 waves = 128 rows x one 128-code slice.  The codebook is the MFMA A operand (code on the
+// row index i), x the B operand (row on the column index j = lane & 31), so every lane owns ONE x row
+// and sees 16 codes per chunk in its accumulator registers: the running best / runner-up is pure in-lane
+// work.  Arithmetic: each fp32 operand is split into a bf16 pair (v = hi + lo + eps, |eps| <= 2^-18 |v|)
+// and x.k is evaluated as kh.xh + kh.xl + kl.xh on v_mfma_f32_32x32x16_bf16 with fp32 accumulation --
+// 3 bf16 MFMAs (16x the fp32-MFMA rate each) replace 8 fp32 MFMAs.  The score is only a FILTER: its
+// error bound (vq_finalize) decides which rows are re-scored exactly, so the index semantics stay exact.
+typedef __bf16 vq_bf16x8 __attribute__((ext_vector_type(8)));
+
 template <int D>
-__global__ __launch_bounds__(256) void vq_score_kernel(const float* __restrict__ x, const float* __restrict__ cb,
-                                                       const float* __restrict__ mu,
+__global__ __launch_bounds__(256) void vq_score_kernel(const float* __restrict__ x, const __bf16* __restrict__ kh,
+                                                       const __bf16* __restrict__ kl, const float* __restrict__ mu,
                                                        const float* __restrict__ khalf, long long N, int K, int S,
                                                        float* __restrict__ p_best, int* __restrict__ p_idx,
                                                        float* __restrict__ p_second) {
-  constexpr int HD = D / 2;
-  constexpr int LDW = D + 4;                       // +16 B pad: conflict-free ds_read_b128
-  constexpr int F4_PER_CHUNK = VQ_CHUNK * D / 4;   // float4s in one staged chunk
-  constexpr int STAGE = (F4_PER_CHUNK + 255) / 256;
-  __shared__ __attribute__((aligned(16))) float lds[2][VQ_CHUNK * LDW];
+  constexpr int NS = D / 16;                       // k-steps per chunk
+  constexpr int LDW = D + 8;                       // +16 B pad: conflict-free ds_read_b128
+  constexpr int V_PER_TILE = VQ_CHUNK * D / 8;     // 16-byte vectors in one staged 32-code tile (hi or lo)
+  constexpr int STAGE = (2 * V_PER_TILE + 255) / 256;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2][2][VQ_CHUNK * LDW];   // [buffer][hi|lo]
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
@@ -88,39 +94,47 @@ __global__ __launch_bounds__(256) void vq_score_kernel(const float* __restrict__
   const int code0 = slice * VQ_SLICE;
   const int nchunk = min(VQ_SLICE / VQ_CHUNK, (K - code0 + VQ_CHUNK - 1) / VQ_CHUNK);
 
-  // this lane's half row of x -> registers (B operand for every MFMA of the slice)
-  float xb[HD];
-  if (row < N) {
-    const f32x4* src = reinterpret_cast<const f32x4*>(x + row * D + h * HD);
-    const f32x4* msrc = reinterpret_cast<const f32x4*>(mu + h * HD);
+  // this lane's share of its x row, centred and split: dims 16 s + 8 h .. + 7 for every k-step s
+  vq_bf16x8 xh[NS], xl[NS];
 #pragma unroll
-    for (int q = 0; q < HD / 4; ++q) {
-      f32x4 v = src[q] - msrc[q];
-      xb[4 * q] = v.x; xb[4 * q + 1] = v.y; xb[4 * q + 2] = v.z; xb[4 * q + 3] = v.w;
+  for (int s = 0; s < NS; ++s) {
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+    if (row < N) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(x + row * D + 16 * s + 8 * h);
+      const f32x4* msrc = reinterpret_cast<const f32x4*>(mu + 16 * s + 8 * h);
+      v0 = src[0] - msrc[0];
+      v1 = src[1] - msrc[1];
     }
-  } else {
 #pragma unroll
-    for (int q = 0; q < HD; ++q) xb[q] = 0.f;
+    for (int e = 0; e < 8; ++e) {
+      const float v = e < 4 ? v0[e & 3] : v1[e & 3];
+      const __bf16 hi = (__bf16)v;
+      xh[s][e] = hi;
+      xl[s][e] = (__bf16)(v - (float)hi);
+    }
   }
 
   f32x4 stage[STAGE];
   auto load_chunk = [&](int c) {
 #pragma unroll
     for (int r = 0; r < STAGE; ++r) {
-      int f = threadIdx.x + 256 * r;
-      int code = f / (D / 4), col4 = f % (D / 4);
-      int gcode = code0 + c * VQ_CHUNK + code;
+      const int f = threadIdx.x + 256 * r;                 // [hi tile vectors | lo tile vectors]
+      const int which = f / V_PER_TILE, g = f % V_PER_TILE;
+      const int code = g / (D / 8), c8 = g % (D / 8);
+      const int gcode = code0 + c * VQ_CHUNK + code;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (f < F4_PER_CHUNK && gcode < K) v = *reinterpret_cast<const f32x4*>(cb + (size_t)gcode * D + 4 * col4);
+      if (f < 2 * V_PER_TILE && gcode < K)
+        v = *reinterpret_cast<const f32x4*>((which ? kl : kh) + (size_t)gcode * D + 8 * c8);
       stage[r] = v;
     }
   };
   auto store_chunk = [&](int buf) {
 #pragma unroll
     for (int r = 0; r < STAGE; ++r) {
-      int f = threadIdx.x + 256 * r;
-      int code = f / (D / 4), col4 = f % (D / 4);
-      if (f < F4_PER_CHUNK) *reinterpret_cast<f32x4*>(&lds[buf][code * LDW + 4 * col4]) = stage[r];
+      const int f = threadIdx.x + 256 * r;
+      const int which = f / V_PER_TILE, g = f % V_PER_TILE;
+      const int code = g / (D / 8), c8 = g % (D / 8);
+      if (f < 2 * V_PER_TILE) *reinterpret_cast<f32x4*>(&lds[buf][which][code * LDW + 8 * c8]) = stage[r];
     }
   };
 
@@ -144,14 +158,15 @@ __global__ __launch_bounds__(256) void vq_score_kernel(const float* __restrict__
         acc[4 * g + e] = (code < K) ? -khalf[code] : 0.f;
       }
     }
-    const float* arow = &lds[buf][j * LDW + h * HD];
+    const __bf16* ah = &lds[buf][0][j * LDW + 8 * h];
+    const __bf16* al = &lds[buf][1][j * LDW + 8 * h];
 #pragma unroll
-    for (int q = 0; q < HD / 4; ++q) {
-      f32x4 a = *reinterpret_cast<const f32x4*>(arow + 4 * q);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, xb[4 * q], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, xb[4 * q + 1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, xb[4 * q + 2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, xb[4 * q + 3], acc, 0, 0, 0);
+    for (int s = 0; s < NS; ++s) {
+      const vq_bf16x8 fh = *reinterpret_cast<const vq_bf16x8*>(ah + 16 * s);
+      const vq_bf16x8 fl = *reinterpret_cast<const vq_bf16x8*>(al + 16 * s);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, xh[s], acc, 0, 0, 0);   // small terms first
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, xl[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, xh[s], acc, 0, 0, 0);
     }
     // in-lane running best / runner-up; codes visited in increasing order, strict '>' keeps
     // the lowest index among equal scores
@@ -219,14 +234,17 @@ __global__ __launch_bounds__(256) void vq_finalize_kernel(const float* __restric
       second = fmaxf(second, b);
     }
   }
-  // On centred operands x~ = x - mu, k~ = k - mu (norms below are the centred ones):
-  //   |acc_fp32 - acc_exact(x~,k~)| <= gamma_(D+1) * (sum|x~_i k~_i| + |k~|^2/2) + (fp32 error of khalf)
-  //                                 <= 1.05*(D+2)*2^-24 * (|x~| |k~|max + |k~|max^2)      (Cauchy-Schwarz)
-  //   rounding x - mu and k - mu perturbs the distance by <= 2*2^-24 (|x~| + |k~|max)^2, i.e. half of
-  //   that in acc units.
+  // Error of the filter score against the exact acc = x~.k~ - |k~|^2/2 on the centred operands
+  // (norms below are the centred ones, Cauchy-Schwarz turns sums of products into norm products):
+  //   bf16-pair split, three of the four partial products kept:  <= 3.01 * 2^-18 |x~| |k~|
+  //   fp32 accumulation of 3D exact products + the initial term:  <= 1.05 (3D+2) 2^-24 (|x~||k~| + |k~|^2/2)
+  //   fp32 rounding of khalf and of the centring x - mu, k - mu:  <= 2^-24 ((D+2)|k~|^2/2 + (|x~| + |k~|)^2)
+  // with |k~| <= |k~|max; a factor 1.25 of slack covers the MFMA's internal summation order.
   const float kmax2 = __uint_as_float(*kmax2_bits);
   const float xk = sqrtf(xx * kmax2);
-  const float err = 5.9604645e-8f * (1.05f * (float)(D + 2) * (xk + kmax2) + 1.05f * (xx + 2.f * xk + kmax2));
+  const float u24 = 5.9604645e-8f;
+  const float err = 1.25f * (3.01f * 64.f * u24 * xk + 1.05f * (float)(3 * D + 2) * u24 * (xk + 0.5f * kmax2) +
+                             u24 * (0.5f * (float)(D + 2) * kmax2 + xx + 2.f * xk + kmax2));
   const bool ambiguous = !((best - second) > 2.0f * err);  // also catches NaN / inf
   if (ambiguous) {
     if (lane == 0) q_rows[atomicAdd(q_count, 1)] = (int)row;
@@ -438,7 +456,7 @@ __global__ __launch_bounds__(1024) void vq_ema_apply_kernel(float* __restrict__ 
 
 struct VqWorkspace {
   float* khalf; unsigned* kmax2; int* q_count; float* p_best; int* p_idx; float* p_second; int* q_rows;
-  float* mu; float* kc;
+  float* mu; __bf16* kh; __bf16* kl;
 };
 
 static size_t vq_layout(long long N, int K, int D, int S, void* base, VqWorkspace* w) {
@@ -452,7 +470,8 @@ static size_t vq_layout(long long N, int K, int D, int S, void* base, VqWorkspac
   p = take((size_t)N * S * 4); if (w) w->p_second = (float*)p;
   p = take((size_t)N * 4);     if (w) w->q_rows = (int*)p;
   p = take((size_t)D * 4);     if (w) w->mu = (float*)p;
-  p = take((size_t)K * D * 4); if (w) w->kc = (float*)p;
+  p = take((size_t)K * D * 2); if (w) w->kh = (__bf16*)p;
+  p = take((size_t)K * D * 2); if (w) w->kl = (__bf16*)p;
   return off;
 }
 
@@ -485,16 +504,16 @@ extern "C" int smt_vq_forward(const float* x, const float* codebook, const float
   }
   vq_mean_kernel<<<1, 1024, 0, stream>>>(codebook, k_bins, dim, w.mu);
   SMT_CHECK_LAUNCH("vq_mean");
-  vq_prep_kernel<<<(k_bins * 64 + 255) / 256, 256, 0, stream>>>(codebook, w.mu, k_bins, dim, w.kc, w.khalf, w.kmax2);
+  vq_prep_kernel<<<(k_bins * 64 + 255) / 256, 256, 0, stream>>>(codebook, w.mu, k_bins, dim, w.kh, w.kl, w.khalf, w.kmax2);
   SMT_CHECK_LAUNCH("vq_prep");
   const long long tiles = (n_rows + VQ_ROWS_PER_WG - 1) / VQ_ROWS_PER_WG;
   const unsigned grid = (unsigned)(tiles * S);
   if (dim == 128)
-    vq_score_kernel<128><<<grid, 256, 0, stream>>>(x, w.kc, w.mu, w.khalf, n_rows, k_bins, S, w.p_best, w.p_idx, w.p_second);
+    vq_score_kernel<128><<<grid, 256, 0, stream>>>(x, w.kh, w.kl, w.mu, w.khalf, n_rows, k_bins, S, w.p_best, w.p_idx, w.p_second);
   else if (dim == 64)
-    vq_score_kernel<64><<<grid, 256, 0, stream>>>(x, w.kc, w.mu, w.khalf, n_rows, k_bins, S, w.p_best, w.p_idx, w.p_second);
+    vq_score_kernel<64><<<grid, 256, 0, stream>>>(x, w.kh, w.kl, w.mu, w.khalf, n_rows, k_bins, S, w.p_best, w.p_idx, w.p_second);
   else
-    vq_score_kernel<32><<<grid, 256, 0, stream>>>(x, w.kc, w.mu, w.khalf, n_rows, k_bins, S, w.p_best, w.p_idx, w.p_second);
+    vq_score_kernel<32><<<grid, 256, 0, stream>>>(x, w.kh, w.kl, w.mu, w.khalf, n_rows, k_bins, S, w.p_best, w.p_idx, w.p_second);
   SMT_CHECK_LAUNCH("vq_score");
   vq_finalize_kernel<<<(unsigned)((n_rows * 64 + 255) / 256), 256, 0, stream>>>(
       x, codebook, w.mu, row_mask, w.kmax2, w.p_best, w.p_idx, w.p_second, n_rows, dim, S, (long long*)idx, min_dist, x_d,

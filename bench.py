@@ -155,8 +155,15 @@ def main():
         m = cfg.model
         n_rows = args.batch * (args.clip_len // 128)
 
-        def group(names, label, bound, dtype):
-            recs = [k for k in kernels if k["name"].split("_k")[0] in names or k["name"] in names]
+        pmc = {}
+        pmc_path = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                pmc = json.load(f)
+
+        def group(prefixes, label, bound, dtype, pmc_key=None):
+            recs = [k for k in kernels if any(k["name"] == q or k["name"].startswith(q + ":") or
+                                              k["name"].startswith(q + "_k") for q in prefixes)]
             if not recs:
                 return None
             launches = sum(k["launches"] for k in recs)
@@ -167,20 +174,30 @@ def main():
                 achieved, peak, unit = flops / total_us * 1e-6, profiler.PEAK_TFLOPS[dtype], "TFLOP/s"
             else:
                 achieved, peak, unit = nbytes / total_us * 1e-3, profiler.HBM_PEAK_GBS, "GB/s"
+            # HBM bytes per launch from the rocprofv3 PMC passes (profiles/r01_pmc_traffic.json), if recorded
+            traffic = pmc.get(pmc_key, {}).get("hbm_bytes_per_launch") if pmc_key else None
             return {"kernel": label, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                     "frac": achieved / peak, "launches_per_step": launches / args.steps,
                     "avg_us": total_us / launches, "ms_per_step": total_us * 1e-3 / args.steps,
                     "alg_flops_per_launch": flops / launches, "alg_bytes_per_launch": nbytes / launches,
-                    "traffic": None}
+                    "traffic": traffic}
 
         dt = "bf16" if m.get("compute_dtype") == "bf16" else "f32"
-        # dominant kernel by time: the implicit-GEMM conv kernel (forward + data-gradient launches)
-        roofline = group({"conv_fwd", "conv_dgrad"}, "smt::conv_gemm_kernel (forward + data gradient launches)", "mfma", dt)
+        # dominant single kernel by time: the LDS-DMA implicit-GEMM conv kernel (dilated convs, fwd + dgrad)
+        roofline = group({"conv_gemm_dma"}, "smt::conv_gemm_dma_kernel (dilated 128->128 convs, forward + data gradient)",
+                         "mfma", dt, "conv_gemm_dma_kernel")
+        if roofline is None:   # fp32 configuration: everything runs on the generic kernel
+            roofline = group({"conv_gemm"}, "smt::conv_gemm_kernel", "mfma", dt, "conv_gemm_kernel")
         extra_rooflines = {
-            "conv_wgrad": group({"conv_wgrad"}, "smt::conv_wgrad_kernel + reduce", "mfma", dt),
-            "vq_forward": group({"vq_forward"}, "smt_vq_forward (prep, score, finalize, rescore, reduce)", "hbm", "f32"),
+            "conv1x1_dma": group({"conv1x1_dma"}, "smt::conv1x1_dma_kernel (persistent 1x1, HBM-bound)", "hbm", dt,
+                                 "conv1x1_dma_kernel"),
+            "conv_gemm": group({"conv_gemm"}, "smt::conv_gemm_kernel (register-staged generic path)", "mfma", dt,
+                               "conv_gemm_kernel"),
+            "conv_wgrad": group({"conv_wgrad"}, "smt::conv_wgrad{,_dma}_kernel + reduce", "mfma", dt, "conv_wgrad"),
+            "vq_forward": group({"vq_forward"}, "smt_vq_forward (mean, prep, score, finalize, rescore, reduce)", "hbm",
+                                "f32", "vq_forward"),
             "vq_ema_accumulate": group({"vq_ema_accumulate"}, "smt::vq_ema_accumulate_kernel", "hbm", "f32"),
-            "gate_mix": group({"gate_mix_fwd", "gate_mix_bwd"}, "smt::gate_mix_{fwd,bwd}_kernel", "hbm", dt),
+            "gate_mix": group({"gate_mix_fwd", "gate_mix_bwd"}, "smt::gate_mix_{fwd,bwd}_kernel", "hbm", dt, "gate_mix"),
             "stft_loss": group({"stft_loss_fwd", "stft_loss_bwd"}, "smt::stft_loss_{fwd,bwd}_kernel", "hbm", "f32"),
         }
         line = {

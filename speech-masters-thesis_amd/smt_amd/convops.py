@@ -121,8 +121,16 @@ def _tag(desc):
     return f"k{desc.taps}d{desc.dilation}s{desc.stride}o{desc.out_stride}_c{desc.c_in}x{desc.c_out}"
 
 
+def _kernel_of(desc):
+    """Which kernel smt_conv1d_ntc dispatches to (mirrors the rule in csrc/conv.hip)."""
+    if desc.w_swizzled:
+        return "conv1x1_dma" if (desc.taps == 1 and desc.c_in == 128) else "conv_gemm_dma"
+    return "conv_gemm"
+
+
 def _launch(desc, name, flops=0.0, nbytes=0.0):
     dtype = "bf16" if desc.dtype == SMT_BF16 else "f32"
+    name = _kernel_of(desc) + ":" + name.replace("conv_", "")      # e.g. conv_gemm_dma:fwd
     if profiler.DETAIL:
         name = name + "_" + _tag(desc)
     with profiler.region(name, nbytes=nbytes, flops=flops, bound="mfma", dtype=dtype):

@@ -35,6 +35,7 @@ struct ConvArgs {
   int act_out, epi_act;                 // relu+dropout of the OUTPUT (second store) / its derivative as epilogue
   unsigned drop_keys[8]; int site_width; unsigned drop_thresh16; float drop_scale;
   int tiles_per_batch;
+  int rs;   // row stride of the dilation-class decomposition (LDS-DMA kernel), 1 = off
   int dbg;  // ablation switches (SMT_CONV_DBG): 1 no A loads, 2 no W loads, 4 no MFMA, 8 no stores
 };
 
@@ -311,10 +312,13 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst_wave_base)
                                    (void __attribute__((address_space(3)))*)lds_dst_wave_base, 16, 0, 0);
 }
 
+// MW = 32-row tiles per wave: BM = 64 * MW rows per workgroup.  MW = 4 (256 rows) halves the weight
+// stream per output row -- the L2 -> LDS weight DMA (taps x 32 KiB per tile) is what bounds this kernel.
+template <int MW>
 __global__ __launch_bounds__(DMA_NT) void conv_gemm_dma_kernel(ConvArgs p, const __bf16* __restrict__ zero_page) {
   typedef __bf16 T;
-  constexpr int EPV = 8, BM = DMA_BM, BN = DMA_BN, KC = DMA_KC, NT = DMA_NT;
-  constexpr int WN = 4, MW = 2;                 // waves 2 (rows) x 4 (cols); wave tile 64 x 32
+  constexpr int EPV = 8, BM = 64 * MW, BN = DMA_BN, KC = DMA_KC, NT = DMA_NT;
+  constexpr int WN = 4;                         // waves 2 (rows) x 4 (cols); wave tile (32 MW) x 32
   constexpr int ROWB = KC * 2;                  // 256 bytes per LDS row (128 channels)
   constexpr int PITCH_C = BN + EPV;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -322,13 +326,21 @@ __global__ __launch_bounds__(DMA_NT) void conv_gemm_dma_kernel(ConvArgs p, const
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, hh = lane >> 5;
 
-  const int ntiles = p.tiles_per_batch * p.B;
+  const int ntiles = p.tiles_per_batch * p.B * p.rs;
   const int per_xcd = (ntiles + 7) / 8;
   const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (tile >= ntiles) return;
-  const int b = tile / p.tiles_per_batch;
+  // Dilation classes: a conv with dilation d >= 8 is run as d independent DENSE convs over the row
+  // classes t = cls (mod d) (rs = d, taps at distance 1 in the class domain), so the halo of a 128-row
+  // tile is (taps - 1) rows instead of (taps - 1) * d.  Each class row is still a whole 256-byte
+  // segment for the DMA.  rs == 1 is the plain case.
+  const int rs = p.rs;
+  const int bb = tile / p.tiles_per_batch;
+  const int b = bb / rs, cls = bb - b * rs;
   const int t0 = (tile % p.tiles_per_batch) * BM;
   const int n0 = blockIdx.y * BN;
+  const int Tc = (p.Tout - cls + rs - 1) / rs;          // rows of this class
+  if (t0 >= Tc) return;
 
   const int rows_in = (BM - 1) + (p.taps - 1) * p.dil + 1;
   const int rows_pad = (rows_in + 3) & ~3;      // DMA granularity: 4 rows (1 KiB) per wave-instruction
@@ -337,9 +349,11 @@ __global__ __launch_bounds__(DMA_NT) void conv_gemm_dma_kernel(ConvArgs p, const
   unsigned char* lds_w = smem + a_bytes;        // 2 x [BN rows][256 B]
   T* lds_c = reinterpret_cast<T*>(smem);
 
-  const T* xg = reinterpret_cast<const T*>(p.x) + (long long)b * p.x_bs;
+  const T* xg = reinterpret_cast<const T*>(p.x) + (long long)b * p.x_bs + (long long)cls * p.ldx;
+  const long long ldx = (long long)p.ldx * rs;
   const unsigned char* wg = reinterpret_cast<const unsigned char*>(p.w);
-  const int len_in = p.lens_in ? min(p.lens_in[b], p.Tin) : p.Tin;
+  const int len_full = p.lens_in ? min(p.lens_in[b], p.Tin) : p.Tin;
+  const int len_in = max(0, (len_full - cls + rs - 1) / rs);
   const int tin0 = t0 - p.pad;
   const int ncc = p.Cin / KC;
 
@@ -359,12 +373,13 @@ __global__ __launch_bounds__(DMA_NT) void conv_gemm_dma_kernel(ConvArgs p, const
   bool okv[NE];
 #pragma unroll
   for (int it = 0; it < NE; ++it) {
-    const int t = t0 + row0 + it * (NT / CV);
-    okv[it] = (t < p.Tout);
+    const int tc = t0 + row0 + it * (NT / CV);
+    okv[it] = (tc < Tc);
+    const long long t = cls + (long long)rs * tc;          // actual row
 #pragma unroll
     for (int e = 0; e < EPV; ++e) { rv[it].v[e] = (T)0.f; uv[it].v[e] = (T)0.f; }
-    if (rg && okv[it]) rv[it] = *reinterpret_cast<const Vec<T, EPV>*>(rg + (long long)t * p.ldr + col);
-    if (p.epi_act && okv[it]) uv[it] = *reinterpret_cast<const Vec<T, EPV>*>(hg + (long long)t * p.ldgh + col);
+    if (rg && okv[it]) rv[it] = *reinterpret_cast<const Vec<T, EPV>*>(rg + t * p.ldr + col);
+    if (p.epi_act && okv[it]) uv[it] = *reinterpret_cast<const Vec<T, EPV>*>(hg + t * p.ldgh + col);
   }
 
   const int lrow = lane >> 4, lch = lane & 15;  // this lane's (row within the 4-row group, chunk) of a DMA instruction
@@ -384,7 +399,7 @@ __global__ __launch_bounds__(DMA_NT) void conv_gemm_dma_kernel(ConvArgs p, const
       const int row = 4 * g + lrow;
       const int tin = tin0 + row;
       const bool ok = (row < rows_in) && (tin >= 0) && (tin < len_in);
-      const T* src = ok ? xg + (long long)tin * p.ldx + cc * KC + ((lch ^ (row & 15)) * EPV) : zero_page + lch * EPV;
+      const T* src = ok ? xg + (long long)tin * ldx + cc * KC + ((lch ^ (row & 15)) * EPV) : zero_page + lch * EPV;
       dma16(src, lds_a + g * 1024);
     }
     stage_w(0, cc, 0);
@@ -395,7 +410,7 @@ __global__ __launch_bounds__(DMA_NT) void conv_gemm_dma_kernel(ConvArgs p, const
       if (s + 1 < nsteps) stage_w(s + 1, cc, (s + 1) & 1);
       const unsigned char* wb = lds_w + (size_t)(s & 1) * BN * ROWB + (wn * 32 + r) * ROWB;
       const int bsw = (wn * 32 + r) & 15;
-      const int arow0 = wm * 64 + s * p.dil + r;
+      const int arow0 = wm * (BM / 2) + s * p.dil + r;
 #pragma unroll
       for (int kk = 0; kk < KC / 16; ++kk) {
         const int ch = 2 * kk + hh;
@@ -418,7 +433,7 @@ __global__ __launch_bounds__(DMA_NT) void conv_gemm_dma_kernel(ConvArgs p, const
   for (int i = 0; i < MW; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+      const int row = wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
       lds_c[row * PITCH_C + wn * 32 + r] = (T)(acc[i][e] + bval);
     }
   __syncthreads();
@@ -430,7 +445,7 @@ __global__ __launch_bounds__(DMA_NT) void conv_gemm_dma_kernel(ConvArgs p, const
 #pragma unroll
   for (int it = 0; it < NE; ++it) {
     const int row = row0 + it * (NT / CV);
-    const int ty = t0 + row;
+    const int ty = cls + rs * (t0 + row);                  // actual output row
     Vec<T, EPV> c = *reinterpret_cast<const Vec<T, EPV>*>(lds_c + row * PITCH_C + cv0 * EPV);
     float o[EPV];
 #pragma unroll
@@ -640,16 +655,34 @@ static bool conv_dma_eligible(const smt_conv_desc* d) {
 }
 
 static int launch_conv_dma(ConvArgs p, const void* zero_page, hipStream_t stream) {
-  p.tiles_per_batch = (p.Tout + DMA_BM - 1) / DMA_BM;
-  const int ntiles = p.tiles_per_batch * p.B;
-  dim3 grid((unsigned)(8 * ((ntiles + 7) / 8)), (unsigned)(p.Cout / DMA_BN));
-  const int rows_in = (DMA_BM - 1) + (p.taps - 1) * p.dil + 1;
-  const int rows_pad = (rows_in + 3) & ~3;
-  const size_t a_bytes = align_up((size_t)std::max(rows_pad * 256, DMA_BM * (DMA_BN + 8) * 2), 1024);
-  const size_t lds = a_bytes + (size_t)(p.taps > 1 ? 2 : 1) * DMA_BN * 256;   // one weight buffer suffices for 1x1
+  // Dilation classes (see the kernel) for same-size convs whose padding is a multiple of a large dilation,
+  // as long as a class still has enough rows to fill tiles.
+  p.rs = 1;
+  if (p.dil >= 8 && p.taps > 1 && p.pad % p.dil == 0 && p.Tin == p.Tout && p.Tout / p.dil >= 512) {
+    p.rs = p.dil; p.pad /= p.dil; p.dil = 1;
+  }
+  const int tc_max = (p.Tout + p.rs - 1) / p.rs;
+  auto lds_for = [&](int bm) {
+    const int rows_in = (bm - 1) + (p.taps - 1) * p.dil + 1;
+    const int rows_pad = (rows_in + 3) & ~3;
+    const size_t a_bytes = align_up((size_t)std::max(rows_pad * 256, bm * (DMA_BN + 8) * 2), 1024);
+    return a_bytes + (size_t)(p.taps > 1 ? 2 : 1) * DMA_BN * 256;   // one weight buffer suffices for 1x1
+  };
+  // 256-row tiles when they fit in LDS and there are enough rows to keep every CU busy
+  const bool big = p.taps > 1 && lds_for(256) <= 160 * 1024 && (long long)tc_max * p.B * p.rs >= 256LL * 256 * 2;
+  const int bm = big ? 256 : 128;
+  const size_t lds = lds_for(bm);
   SMT_CHECK_ARG(lds <= 160 * 1024, "conv_gemm_dma: tile needs %zu B of LDS", lds);
-  (void)hipFuncSetAttribute((const void*)conv_gemm_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  conv_gemm_dma_kernel<<<grid, DMA_NT, lds, stream>>>(p, (const __bf16*)zero_page);
+  p.tiles_per_batch = (tc_max + bm - 1) / bm;
+  const int ntiles = p.tiles_per_batch * p.B * p.rs;
+  dim3 grid((unsigned)(8 * ((ntiles + 7) / 8)), (unsigned)(p.Cout / DMA_BN));
+  if (big) {
+    (void)hipFuncSetAttribute((const void*)conv_gemm_dma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    conv_gemm_dma_kernel<4><<<grid, DMA_NT, lds, stream>>>(p, (const __bf16*)zero_page);
+  } else {
+    (void)hipFuncSetAttribute((const void*)conv_gemm_dma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    conv_gemm_dma_kernel<2><<<grid, DMA_NT, lds, stream>>>(p, (const __bf16*)zero_page);
+  }
   SMT_CHECK_LAUNCH("conv_gemm_dma");
   return 0;
 }
@@ -770,6 +803,7 @@ extern "C" int smt_conv1d_ntc(const smt_conv_desc* d, smt_stream_t stream_) {
   for (int i = 0; i < 8; ++i) p.drop_keys[i] = d->drop_keys[i];
   p.site_width = d->site_width; p.drop_thresh16 = d->drop_thresh16; p.drop_scale = d->drop_scale;
   p.tiles_per_batch = 0;
+  p.rs = 1;
   { static int dbg = getenv("SMT_CONV_DBG") ? atoi(getenv("SMT_CONV_DBG")) : 0; p.dbg = dbg; }
   if (conv_dma_eligible(d) && d->taps == 1 && d->c_in == 128) return launch_conv1x1_dma(p, d->zero_page, stream);
   if (conv_dma_eligible(d)) {

@@ -30,6 +30,7 @@ struct WgradArgs {
   int B, Tin, Tout, Ty, Cin, Cout;
   int taps, stride, dil, pad, out_stride, out_offset;
   int rows_per_chunk, chunks_per_batch, nblk_ci, nblk_co, with_bias;
+  int rs;   // dilation-class row stride (LDS-DMA kernel), 1 = off
 };
 
 // R = rows per staged tile; CIB = input channels per workgroup (CIB/32 wave columns, 2 wave rows);
@@ -258,19 +259,26 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(WgradArgs p, const 
   const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
   const int blk = q % nblk;
   const int cgl = (q / nblk) * 8 + xcd;
-  if (cgl >= p.B * p.chunks_per_batch) return;
+  if (cgl >= p.B * p.rs * p.chunks_per_batch) return;
   const int co0 = (blk / p.nblk_ci) * CB, ci0 = (blk % p.nblk_ci) * CIB;
-  const int b = cgl / p.chunks_per_batch;
+  // dilation classes (see conv_gemm_dma_kernel): rs > 1 runs the dilated conv as rs dense convs over the
+  // row classes t = cls (mod rs); a "batch item" here is one (batch, class) pair
+  const int rs = p.rs;
+  const int bb = cgl / p.chunks_per_batch;
+  const int b = bb / rs, cls = bb - b * rs;
   const int chunk = cgl % p.chunks_per_batch;
+  const int Tc = (p.Tout - cls + rs - 1) / rs;
   const int t_begin = chunk * p.rows_per_chunk;
-  const int t_end = min(p.Tout, t_begin + p.rows_per_chunk);
+  const int t_end = min(Tc, t_begin + p.rows_per_chunk);
 
   const int rows_x = (R - 1) + (p.taps - 1) * p.dil + 1;
   const int rows_x_pad = (rows_x + 3) & ~3;
   const size_t buf_bytes = (size_t)DY_BYTES + (size_t)rows_x_pad * XB;
-  const T* xg = reinterpret_cast<const T*>(p.x) + (long long)b * p.x_bs;
-  const T* dyg = reinterpret_cast<const T*>(p.dy) + (long long)b * p.dy_bs;
-  const int len_in = p.lens_in ? min(p.lens_in[b], p.Tin) : p.Tin;
+  const T* xg = reinterpret_cast<const T*>(p.x) + (long long)b * p.x_bs + (long long)cls * p.ldx;
+  const T* dyg = reinterpret_cast<const T*>(p.dy) + (long long)b * p.dy_bs + (long long)cls * p.ldy;
+  const long long ldx = (long long)p.ldx * rs, ldy = (long long)p.ldy * rs;
+  const int len_full = p.lens_in ? min(p.lens_in[b], p.Tin) : p.Tin;
+  const int len_in = max(0, (len_full - cls + rs - 1) / rs);
   const bool bias_plane = p.with_bias && (ci0 == 0);
   const int ntaps = p.taps;
 
@@ -288,7 +296,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(WgradArgs p, const 
       const int t = t0 + row;
       const bool ok = t < t_end;
       const int ch = pos ^ (((row >> 1) & 1) << 2);
-      const T* src = ok ? dyg + (long long)t * p.ldy + co0 + ch * 8 : zero_page + pos * 8;
+      const T* src = ok ? dyg + (long long)t * ldy + co0 + ch * 8 : zero_page + pos * 8;
       wg_dma16(src, base + g * 1024);
     }
     // x: rows_x_pad rows x 16 chunks; one wave-instruction = 4 rows
@@ -298,7 +306,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(WgradArgs p, const 
       const int tin = tin0 + row;
       const bool ok = (row < rows_x) && (tin >= 0) && (tin < len_in);
       const int ch = pos ^ ((row & 3) << 2);
-      const T* src = ok ? xg + (long long)tin * p.ldx + ci0 + ch * 8 : zero_page + pos * 8;
+      const T* src = ok ? xg + (long long)tin * ldx + ci0 + ch * 8 : zero_page + pos * 8;
       wg_dma16(src, base + DY_BYTES + g * 1024);
     }
   };
@@ -410,19 +418,32 @@ static int wgrad_cib(const smt_conv_desc* d) {
   return (d->c_in > 64 && d->stride == 1) ? 128 : 64;
 }
 
+// dilation-class decomposition applies to the LDS-DMA variant only (bf16, 128-channel blocks, stride 1)
+static int wgrad_rs(const smt_conv_desc* d) {
+  const bool dma_shape = d->dtype == SMT_BF16 && d->stride == 1 && d->c_in % 128 == 0 && d->c_out % 64 == 0 &&
+                         d->out_stride == 1 && d->out_offset == 0 && d->zero_page != nullptr;
+  // Measured: for the weight gradient the strided class rows cost more than the smaller halo saves
+  // (2.04 vs 1.79 ms at k = 9, dilation 27, T/2 level), so the decomposition stays switched off here.
+  constexpr bool kUseClasses = false;
+  return (kUseClasses && dma_shape && d->dilation >= 8 && d->taps > 1 && d->padding % d->dilation == 0 &&
+          d->t_in == d->t_out) ? d->dilation : 1;
+}
+
 static void wgrad_plan(const smt_conv_desc* d, int* rows_per_chunk, int* chunks_per_batch, int* nblk_co,
                        int* nblk_ci, int* planes) {
   const int cib = wgrad_cib(d);
+  const int rs = wgrad_rs(d);
   *nblk_co = (d->c_out + 63) / 64;
   *nblk_ci = (d->c_in + cib - 1) / cib;
   const int R = d->dtype == SMT_BF16 ? 128 : 64;
-  long long total_rows = (long long)d->batch * d->t_out;
+  const long long tc = (d->t_out + rs - 1) / rs;                 // rows per (batch, class) item
+  long long total_rows = (long long)d->batch * rs * tc;
   long long target_wgs = 512;   // two rounds of one workgroup per CU: keeps the partial slabs small
   long long rows = (total_rows * (*nblk_co) * (*nblk_ci) + target_wgs - 1) / target_wgs;
   rows = std::max<long long>(R, (rows + R - 1) / R * R);
-  rows = std::min<long long>(rows, ((long long)d->t_out + R - 1) / R * R);
+  rows = std::min<long long>(rows, (tc + R - 1) / R * R);
   *rows_per_chunk = (int)rows;
-  *chunks_per_batch = (int)((d->t_out + rows - 1) / rows);
+  *chunks_per_batch = (int)((tc + rows - 1) / rows);
   *planes = d->taps + 1;
 }
 
@@ -433,7 +454,7 @@ using namespace smt;
 static size_t wgrad_group_ws(const smt_conv_desc* d) {
   int rpc, cpb, nco, nci, planes;
   wgrad_plan(d, &rpc, &cpb, &nco, &nci, &planes);
-  return (size_t)d->batch * cpb * nco * nci * planes * 64 * wgrad_cib(d) * sizeof(float);
+  return (size_t)d->batch * wgrad_rs(d) * cpb * nco * nci * planes * 64 * wgrad_cib(d) * sizeof(float);
 }
 
 // Tap groups: more than 5 taps would need more accumulator registers than two waves per SIMD allow,
@@ -495,12 +516,15 @@ static int wgrad_group(const smt_conv_desc* d, float* dweight, int64_t stride_ou
   a.taps = d->taps; a.stride = d->stride; a.dil = d->dilation; a.pad = d->padding;
   a.out_stride = d->out_stride; a.out_offset = d->out_offset;
   a.rows_per_chunk = rpc; a.chunks_per_batch = cpb; a.nblk_ci = nci; a.nblk_co = nco; a.with_bias = dbias ? 1 : 0;
+  const int rs = wgrad_rs(d);
+  a.rs = rs;
+  if (rs > 1) { a.pad = d->padding / rs; a.dil = 1; }
   if (d->batch > 0 && d->t_out > 0) {
-    const int n_chunks = d->batch * cpb;
+    const int n_chunks = d->batch * rs * cpb;
     dim3 grid((unsigned)(8 * ((n_chunks + 7) / 8) * nco * nci));
     const bool bf = d->dtype == SMT_BF16;
     const int R = bf ? 128 : 64;
-    const int rows_x = (R - 1) * d->stride + (d->taps - 1) * d->dilation + 1;
+    const int rows_x = (R - 1) * d->stride + (d->taps - 1) * a.dil + 1;
     const size_t lds = bf ? ((size_t)R * WTr<__bf16>::pitch(64) + (size_t)rows_x * WTr<__bf16>::pitch(cib)) * 2
                           : ((size_t)R * WTr<float>::pitch(64) + (size_t)rows_x * WTr<float>::pitch(cib)) * 4;
     SMT_CHECK_ARG(lds <= 160 * 1024, "conv_wgrad: tile needs %zu B of LDS", lds);
@@ -510,6 +534,7 @@ static int wgrad_group(const smt_conv_desc* d, float* dweight, int64_t stride_ou
     const size_t lds_dma = 2 * ((size_t)128 * 128 + (size_t)rows_xp * 256);
     const bool dma = bf && cib == 128 && !strided && d->zero_page && d->c_in % 128 == 0 && d->c_out % 64 == 0 &&
                      d->out_stride == 1 && d->out_offset == 0 && lds_dma <= 160 * 1024;
+    SMT_CHECK_ARG(rs == 1 || dma, "conv_wgrad: dilation classes need the LDS-DMA variant");
     if (dma) {
 #define SMT_WGD_CASE(NT)                                                                                 \
   case NT:                                                                                               \
@@ -534,7 +559,7 @@ static int wgrad_group(const smt_conv_desc* d, float* dweight, int64_t stride_ou
   }
   WreduceArgs r;
   r.slab = (const float*)workspace; r.dw = dweight; r.db = dbias;
-  r.n_chunks = d->batch * cpb; r.nblk = nco * nci; r.nblk_ci = nci; r.planes = planes; r.taps = d->taps;
+  r.n_chunks = d->batch * rs * cpb; r.nblk = nco * nci; r.nblk_ci = nci; r.planes = planes; r.taps = d->taps;
   r.Cin = d->c_in; r.Cout = d->c_out; r.with_bias = dbias ? 1 : 0; r.cib = cib;
   r.so = stride_out; r.si = stride_in; r.sj = stride_tap;
   for (int t = 0; t < d->taps; ++t) r.jmap[t] = tap_map[t];

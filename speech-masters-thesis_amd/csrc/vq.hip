@@ -271,33 +271,51 @@ __global__ __launch_bounds__(256) void vq_finalize_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------- rescore ---
-// Exact fp64 re-scoring of queued rows over ALL codes: d_j = sum_i (x_i - k_ji)^2
-// accumulated in index order without fma contraction (== numpy float64 loop of
-// the oracle).  One workgroup per queued row, grid-stride over the queue.
+// Exact fp64 re-scoring of queued rows over ALL codes: d_j = sum_i (x_i - k_ji)^2 accumulated in index
+// order without fma contraction (== the numpy float64 loop of the oracle).  One workgroup per queued
+// row, grid-stride over the queue; thread t owns code (block*256 + t).  Codebook blocks are staged
+// through LDS ([256 codes][64 dims], pitch 65 floats) so that the global reads are coalesced 16-byte
+// accesses and every thread then walks ITS code's dims conflict-free.
 __global__ __launch_bounds__(256) void vq_rescore_kernel(const float* __restrict__ x, const float* __restrict__ cb,
                                                          const float* __restrict__ row_mask, long long N, int K, int D,
                                                          const int* __restrict__ q_count, const int* __restrict__ q_rows,
                                                          long long* __restrict__ idx, float* __restrict__ min_dist,
                                                          float* __restrict__ x_d) {
+  constexpr int HB = 64, PITCH = 65;
   __shared__ double xs[256];
+  __shared__ float tile[256 * PITCH];
   __shared__ double red_d[256];
   __shared__ int red_i[256];
   const int n_q = *q_count;
+  const int halves = (D + HB - 1) / HB;
   for (int q = blockIdx.x; q < n_q; q += gridDim.x) {
     const long long row = q_rows[q];
     __syncthreads();
     if (threadIdx.x < D) xs[threadIdx.x] = (double)x[row * D + threadIdx.x];
-    __syncthreads();
     double bd = INFINITY;
     int bi = 0x7fffffff;
-    for (int code = threadIdx.x; code < K; code += 256) {
-      const float* kr = cb + (size_t)code * D;
+    for (int c0 = 0; c0 < K; c0 += 256) {
       double acc = 0.0;
-      for (int i = 0; i < D; ++i) {
-        double df = __dsub_rn(xs[i], (double)kr[i]);
-        acc = __dadd_rn(acc, __dmul_rn(df, df));
+      for (int hf = 0; hf < halves; ++hf) {
+        const int d0 = hf * HB, dn = min(HB, D - d0);          // dims [d0, d0 + dn), dn % 4 == 0
+        __syncthreads();
+        const int v_per_code = dn / 4;
+        for (int f = threadIdx.x; f < 256 * v_per_code; f += 256) {
+          const int code = f / v_per_code, c4 = f % v_per_code;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (c0 + code < K) v = *reinterpret_cast<const f32x4*>(cb + (size_t)(c0 + code) * D + d0 + 4 * c4);
+          float* dst = &tile[code * PITCH + 4 * c4];
+          dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+        __syncthreads();
+        const float* kr = &tile[threadIdx.x * PITCH];
+        for (int i = 0; i < dn; ++i) {
+          double df = __dsub_rn(xs[d0 + i], (double)kr[i]);
+          acc = __dadd_rn(acc, __dmul_rn(df, df));
+        }
       }
-      if (acc < bd) { bd = acc; bi = code; }  // increasing code order: lowest index on ties
+      const int code = c0 + threadIdx.x;
+      if (code < K && acc < bd) { bd = acc; bi = code; }        // increasing code order: lowest index on ties
     }
     red_d[threadIdx.x] = bd;
     red_i[threadIdx.x] = bi;
@@ -317,8 +335,7 @@ __global__ __launch_bounds__(256) void vq_rescore_kernel(const float* __restrict
     if (x_d && threadIdx.x < D) x_d[row * D + threadIdx.x] = cb[(size_t)wi * D + threadIdx.x] * m;
     if (threadIdx.x == 0) {
       idx[row] = wi;
-      // fp32 direct form, same arithmetic as vq_finalize (lane-strided fma chains + wave tree)
-      min_dist[row] = (float)red_d[0];
+      min_dist[row] = (float)red_d[0];   // the exact distance, rounded once
     }
   }
 }
@@ -519,7 +536,7 @@ extern "C" int smt_vq_forward(const float* x, const float* codebook, const float
       x, codebook, w.mu, row_mask, w.kmax2, w.p_best, w.p_idx, w.p_second, n_rows, dim, S, (long long*)idx, min_dist, x_d,
       w.q_count, w.q_rows);
   SMT_CHECK_LAUNCH("vq_finalize");
-  vq_rescore_kernel<<<256, 256, 0, stream>>>(x, codebook, row_mask, n_rows, k_bins, dim, w.q_count, w.q_rows,
+  vq_rescore_kernel<<<512, 256, 0, stream>>>(x, codebook, row_mask, n_rows, k_bins, dim, w.q_count, w.q_rows,
                                              (long long*)idx, min_dist, x_d);
   SMT_CHECK_LAUNCH("vq_rescore");
   vq_reduce_kernel<<<1, 1024, 0, stream>>>(min_dist, row_mask, n_rows, w.q_count, sums);

@@ -127,6 +127,9 @@ typedef struct smt_conv_desc {
   const void* zero_page;           /* >= 256 zero bytes in device memory (source of out-of-range rows), or NULL */
 } smt_conv_desc;
 int smt_conv1d_ntc(const smt_conv_desc* desc, smt_stream_t stream);
+/* Name of the kernel smt_conv1d_ntc dispatches this descriptor to ("conv_gemm", "conv_gemm_dma", "conv_ws",
+ * "conv1x1_dma"): for profilers and tests; no device work. */
+const char* smt_conv1d_kernel_name(const smt_conv_desc* desc);
 
 /* Weight (+ bias) gradient of the same convolution:
  *   dw[j][co][ci] = sum_{b,t} dy[b, t*out_stride + out_offset, co] * x[b, t*stride + j*dil - pad, ci]

@@ -306,6 +306,10 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(ConvArgs p) {
 //   weights    : pre-swizzled in global memory by smt_pack_weight(swizzle = 1), copied linearly.
 // Rows outside [0, len) are fetched from a zero page.
 constexpr int DMA_BM = 128, DMA_BN = 128, DMA_KC = 128, DMA_NT = 512;
+#ifndef SMT_ABL
+#define SMT_ABL 0   // ablation build switches for conv_gemm_dma_kernel (tools/ablate_dma.sh); 0 in the product
+#endif
+constexpr int ABL = SMT_ABL;
 
 __device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst_wave_base) {
   __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,
@@ -395,6 +399,7 @@ __global__ __launch_bounds__(DMA_NT) void conv_gemm_dma_kernel(ConvArgs p, const
 
   for (int cc = 0; cc < ncc; ++cc) {
     __syncthreads();  // previous chunk's readers are done with lds_a / lds_w
+    if (!(ABL & 1))
     for (int g = wave; g < rows_pad / 4; g += NT / 64) {
       const int row = 4 * g + lrow;
       const int tin = tin0 + row;
@@ -407,19 +412,26 @@ __global__ __launch_bounds__(DMA_NT) void conv_gemm_dma_kernel(ConvArgs p, const
     __syncthreads();
     const int nsteps = p.taps;
     for (int s = 0; s < nsteps; ++s) {
-      if (s + 1 < nsteps) stage_w(s + 1, cc, (s + 1) & 1);
+      if (s + 1 < nsteps && !(ABL & 2)) stage_w(s + 1, cc, (s + 1) & 1);
       const unsigned char* wb = lds_w + (size_t)(s & 1) * BN * ROWB + (wn * 32 + r) * ROWB;
       const int bsw = (wn * 32 + r) & 15;
       const int arow0 = wm * (BM / 2) + s * p.dil + r;
+      bf16x8 bv0, av0[MW];
+      if (ABL & 16) bv0 = *reinterpret_cast<const bf16x8*>(wb + ((hh ^ bsw) << 4));
+      if (ABL & 8) {
+#pragma unroll
+        for (int i = 0; i < MW; ++i) av0[i] = *reinterpret_cast<const bf16x8*>(lds_a + (arow0 + 32 * i) * ROWB + ((hh ^ ((arow0 + 32 * i) & 15)) << 4));
+      }
 #pragma unroll
       for (int kk = 0; kk < KC / 16; ++kk) {
         const int ch = 2 * kk + hh;
-        bf16x8 bv = *reinterpret_cast<const bf16x8*>(wb + ((ch ^ bsw) << 4));
+        bf16x8 bv = (ABL & 16) ? bv0 : *reinterpret_cast<const bf16x8*>(wb + ((ch ^ bsw) << 4));
 #pragma unroll
         for (int i = 0; i < MW; ++i) {
           const int ar = arow0 + 32 * i;
-          bf16x8 av = *reinterpret_cast<const bf16x8*>(lds_a + ar * ROWB + ((ch ^ (ar & 15)) << 4));
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i], 0, 0, 0);
+          bf16x8 av = (ABL & 8) ? av0[i] : *reinterpret_cast<const bf16x8*>(lds_a + ar * ROWB + ((ch ^ (ar & 15)) << 4));
+          if (ABL & 4) asm volatile("" ::"v"(av), "v"(bv));
+          else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i], 0, 0, 0);
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -634,6 +646,278 @@ __global__ __launch_bounds__(DMA_NT) void conv1x1_dma_kernel(ConvArgs p, const _
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight-stationary variant (bf16, C_in == 128, 3..9 taps): the k x 128 x 128 weight block of a dilated conv
+// is at most 288 KiB -- too large for LDS, but it fits the REGISTER FILE of one CU.  Four waves (one per
+// SIMD, up to 512 VGPRs each) each own 32 output channels and keep that slice of every tap in registers
+// for the whole run of a persistent workgroup, so nothing but activations moves through LDS:
+//   * activation tiles (128 rows + halo) arrive by LDS-DMA into a double buffer: tile i+1 and the epilogue
+//     operands of tile i are in flight while tile i is multiplied, and the stores of tile i-1 drain;
+//   * ONE barrier per tile (the buffer swap); the tap loop has none;
+//   * the MFMA computes the TRANSPOSED tile (A = weights, B = activations), so a lane ends up with 4
+//     consecutive output channels of one row; a v_permlane32_swap pairs them to 16-byte pieces that are stored
+//     straight from registers -- no LDS staging of the output, no epilogue barrier;
+//   * each wave DMAs its own 64-byte column slice of the residual / activation-source rows to LDS and reads
+//     only that back, so the epilogue operands need neither registers during the tap loop nor a barrier.
+// Measured motivation (tools/ablate_dma.sh): the streaming kernel spends as long waiting for HBM (tile in,
+// tile out) as it does in MFMAs, and with one workgroup per CU the two never overlap.
+constexpr int WS_AGPR_TAPS = 7;   // taps whose weights are pinned to AccVGPRs (7 x 32 = 224 of 256)
+constexpr int WS_BM = 128, WS_NT = 256, WS_EPI = 128 * 256;   // rows per tile, threads, epilogue-operand tile bytes
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
+}
+
+template <int NTAPS>
+__global__ __launch_bounds__(WS_NT) void conv_ws_kernel(ConvArgs p, const __bf16* __restrict__ zero_page,
+                                                        int tiles_per_wg, int buf_bytes) {
+  typedef __bf16 T;
+  constexpr int EPV = 8, BM = WS_BM, BN = 128, KC = 128, NT = WS_NT, MW = BM / 32, ROWB = KC * 2;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int lrow = lane >> 4, lch = lane & 15;
+  const int n0 = blockIdx.y * BN;
+  const int rs = p.rs;
+
+  const int ntiles = p.tiles_per_batch * p.B * rs;
+  const int nwg = gridDim.x;
+  const int wg = (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3);
+  const int tile_begin = wg * tiles_per_wg;
+  const int tile_end = min(ntiles, tile_begin + tiles_per_wg);
+  if (tile_begin >= tile_end) return;
+
+  // epilogue-operand tiles: per wave [128 rows][64 B] (its 32 output channels), 16-byte chunks XOR-swizzled
+  unsigned char* lds_res = smem + 2 * (size_t)buf_bytes + wave * (WS_EPI / 4);
+  unsigned char* lds_act = lds_res + WS_EPI;
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+  // this wave's 32 output channels of every tap -> registers (packed swizzled: chunk c of row co at c ^ (co & 15))
+  bf16x8 wfrag[NTAPS][KC / 16];
+  {
+    const int co = n0 + wave * 32 + r;
+#pragma unroll
+    for (int s = 0; s < NTAPS; ++s) {
+      const unsigned char* wrow = reinterpret_cast<const unsigned char*>(p.w) + ((size_t)s * p.Cout + co) * ROWB;
+#pragma unroll
+      for (int kk = 0; kk < KC / 16; ++kk)
+        wfrag[s][kk] = *reinterpret_cast<const bf16x8*>(wrow + (((2 * kk + hh) ^ (co & 15)) << 4));
+    }
+  }
+  // accumulator element 4g + k of a lane = output channel col0 + 8g + k (this lane's row: 32 i + r)
+  const int col0 = n0 + wave * 32 + 4 * hh;
+  float bval[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) bval[e] = p.bias ? p.bias[col0 + 8 * (e >> 2) + (e & 3)] : 0.f;
+  const int rows_in = BM + (NTAPS - 1) * p.dil;
+  const int rows_pad = (rows_in + 3) & ~3;
+
+  // tile -> (batch, class, first class row)
+  auto decode = [&](int tile, int& b, int& cls, int& t0) {
+    const int bb = tile / p.tiles_per_batch;
+    b = bb / rs; cls = bb - b * rs;
+    t0 = (tile - bb * p.tiles_per_batch) * BM;
+  };
+  auto stage_a = [&](int tile, int buf) {
+    int b, cls, t0;
+    decode(tile, b, cls, t0);
+    const T* xg = reinterpret_cast<const T*>(p.x) + (long long)b * p.x_bs + (long long)cls * p.ldx;
+    const long long ldx = (long long)p.ldx * rs;
+    const int len_full = p.lens_in ? min(p.lens_in[b], p.Tin) : p.Tin;
+    const int len_in = max(0, (len_full - cls + rs - 1) / rs);
+    const int tin0 = t0 - p.pad;
+    for (int g = wave; g < rows_pad / 4; g += NT / 64) {
+      const int row = 4 * g + lrow;
+      const int tin = tin0 + row;
+      const bool ok = (row < rows_in) && (tin >= 0) && (tin < len_in);
+      const T* src = ok ? xg + (long long)tin * ldx + ((lch ^ (row & 15)) * EPV) : zero_page + lch * EPV;
+      dma16(src, smem + (size_t)buf * buf_bytes + g * 1024);
+    }
+  };
+  // this wave's slice of an epilogue operand: one DMA instruction = 16 rows x 64 B; slot c of row n holds the
+  // 16-byte chunk c ^ ((n >> 2) & 3) of the slice (keeps the 8-byte fragment reads at <= 2-way bank conflicts)
+  auto stage_epi = [&](const T* base, long long bs, int ld, int b, int cls, int t0, int Tc, unsigned char* dst) {
+    const T* g0 = base + (long long)b * bs + n0 + wave * 32;
+#pragma unroll
+    for (int q = 0; q < BM / 16; ++q) {
+      const int row = 16 * q + (lane >> 2), slot = lane & 3;
+      const int tc = t0 + row;
+      const int chunk = slot ^ ((row >> 2) & 3);
+      const T* src = (tc < Tc) ? g0 + (long long)(cls + (long long)rs * tc) * ld + chunk * EPV : zero_page + slot * EPV;
+      dma16(src, dst + q * 1024);
+    }
+  };
+
+  stage_a(tile_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    const int buf = (tile - tile_begin) & 1;
+    int b, cls, t0;
+    decode(tile, b, cls, t0);
+    const int Tc = (p.Tout - cls + rs - 1) / rs;
+    // tile `tile` is in LDS for every wave (each waited for its own DMAs before its previous epilogue) and
+    // every wave is done reading the other buffer
+    __syncthreads();
+    if (tile + 1 < tile_end) stage_a(tile + 1, buf ^ 1);
+    if (p.res) stage_epi(reinterpret_cast<const T*>(p.res), p.res_bs, p.ldr, b, cls, t0, Tc, lds_res);
+    if (p.epi_act) stage_epi(reinterpret_cast<const T*>(p.gate_h), p.gh_bs, p.ldgh, b, cls, t0, Tc, lds_act);
+
+    f32x16 acc[MW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    // Software pipeline over the NTAPS x 8 k-steps, written as asm so that it stays a pipeline: the four
+    // fragments of step q+1 are requested before the four MFMAs of step q (one wave per SIMD -- nothing else
+    // hides the LDS latency) and `s_waitcnt lgkmcnt(4)` retires exactly the older four (LDS returns in order;
+    // a stray scalar load in flight only makes the wait more conservative).  The asm also pins the register
+    // classes: the first WS_AGPR_TAPS taps of the weight block live in AccVGPRs and are read directly as an
+    // operand, the rest and the accumulators in VGPRs.  Left to itself the compiler keeps all 288 weight
+    // registers in the 256 VGPRs, spills to AccVGPRs, and serialises every ds_read behind the previous MFMA.
+    // fragment address of step (s, kk) = tap_base[s] ^ (32 kk): buffers are 1 KiB-aligned, so the XOR swizzle of
+    // the 16-byte chunk index (bits 4..7) can be applied after the buffer base has been added
+    const unsigned abase = lds_base + (unsigned)buf * (unsigned)buf_bytes;
+    unsigned tap_base[NTAPS];
+#pragma unroll
+    for (int s = 0; s < NTAPS; ++s) {
+      const int ar = r + s * p.dil;                 // rows ar + 32 i share the swizzle term (ar & 15)
+      tap_base[s] = abase + ar * ROWB + ((hh ^ (ar & 15)) << 4);
+    }
+    auto frag_addr = [&](int q) -> unsigned { return tap_base[q / (KC / 16)] ^ (32u * (q % (KC / 16))); };
+    bf16x8 afr[2][MW];
+    if (!(ABL & 4)) {
+    {
+      const unsigned ap = frag_addr(0);
+#pragma unroll
+      for (int i = 0; i < MW; ++i)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(afr[0][i]) : "v"(ap), "n"(i * 32 * ROWB));
+    }
+#pragma unroll
+    for (int q = 0; q < NTAPS * (KC / 16); ++q) {
+      if (q + 1 < NTAPS * (KC / 16)) {
+        const unsigned ap = frag_addr(q + 1);
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(afr[(q + 1) & 1][i]) : "v"(ap), "n"(i * 32 * ROWB));
+        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+#pragma unroll
+      for (int i = 0; i < MW; ++i) {
+        // first use of an accumulator: the compiler may have initialised it with a VALU move in the instruction
+        // just before, and it cannot see that an MFMA follows (VALU write -> MFMA SrcC needs wait states)
+        if (q == 0) asm volatile("s_nop 4" : "+v"(acc[i]));
+        // D^T = W * A^T: operand A = weights [32 co x 16 k], operand B = activations [16 k x 32 rows]
+        if (q / (KC / 16) < WS_AGPR_TAPS)
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "a"(wfrag[q / (KC / 16)][q % (KC / 16)]), "v"(afr[q & 1][i]));
+        else
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(wfrag[q / (KC / 16)][q % (KC / 16)]), "v"(afr[q & 1][i]));
+      }
+    }
+    // The hazard recogniser does not see MFMAs inside asm: let the last ones drain before VALU reads acc.  The
+    // accumulators are operands of the nops so that no reader of acc can be scheduled above them.
+    static_assert(MW == 4, "drain below names four accumulators");
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
+                 : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    }
+    // next tile + this tile's epilogue operands have landed (issued a whole tap loop ago); older stores retired
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ABL & 32) {   // ablation: no epilogue
+      asm volatile("" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
+      continue;
+    }
+
+    // ---- epilogue straight from the accumulators; same arithmetic as the other kernels: bf16(acc + bias) first
+    T* yg = p.y ? reinterpret_cast<T*>(p.y) + (long long)b * p.y_bs : nullptr;
+    T* ug = p.act_out ? reinterpret_cast<T*>(p.y_act) + (long long)b * p.ya_bs : nullptr;
+    const int len_out = p.lens_out ? p.lens_out[b] : 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+      const int row = 32 * i + r;
+      const int tc = t0 + row;
+      const bool ok = tc < Tc;
+      const int ty = cls + rs * tc;                          // actual output row
+      const float keep_row = (ty >= len_out) ? 0.f : 1.f;
+      const int swz = (row >> 2) & 3;
+      unsigned yp[8], up[8];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (float)(T)(acc[i][4 * g + k] + bval[4 * g + k]);
+        const int eoff = row * 64 + ((g ^ swz) << 4) + 8 * hh;
+        if (p.epi_act) {
+          Vec<T, 4> uv = *reinterpret_cast<const Vec<T, 4>*>(lds_act + eoff);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] = ((float)uv.v[k] != 0.f) ? o[k] * p.drop_scale : 0.f;
+        }
+        if (p.res) {
+          Vec<T, 4> rv = *reinterpret_cast<const Vec<T, 4>*>(lds_res + eoff);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] = fmaf(o[k], keep_row, (float)rv.v[k]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] *= keep_row;
+        }
+        yp[2 * g] = pack_bf16x2(o[0], o[1]);
+        yp[2 * g + 1] = pack_bf16x2(o[2], o[3]);
+        if (p.act_out) {
+          const int col = col0 + 8 * g;
+          const int site = col / p.site_width;
+          const unsigned key = p.drop_keys[site & 7];
+          const unsigned long long base = ((unsigned long long)b * p.Ty + ty) * p.site_width + (col - site * p.site_width);
+#pragma unroll
+          for (int k = 0; k < 4; k += 2) {
+            const unsigned h = fmix32((unsigned)((base + k) >> 1) * 0x9E3779B1u + key);
+            const bool k0 = (h & 0xFFFFu) >= p.drop_thresh16, k1 = (h >> 16) >= p.drop_thresh16;
+            up[2 * g + (k >> 1)] = pack_bf16x2((k0 && o[k] > 0.f) ? o[k] * p.drop_scale : 0.f,
+                                               (k1 && o[k + 1] > 0.f) ? o[k + 1] * p.drop_scale : 0.f);
+          }
+        }
+      }
+      // lanes r and r + 32 hold channels {0-3, 8-11, 16-19, 24-27} and {4-7, 12-15, 20-23, 28-31} of the same
+      // row: swap so that lane r owns 0-7 | 16-23 and lane r + 32 owns 8-15 | 24-31 (16-byte pieces)
+      auto pair_up = [&](unsigned* v) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            auto sw = __builtin_amdgcn_permlane32_swap(v[4 * h2 + d], v[4 * h2 + 2 + d], false, false);
+            v[4 * h2 + d] = sw[0]; v[4 * h2 + 2 + d] = sw[1];
+          }
+      };
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const int scol = n0 + wave * 32 + 8 * hh;
+      if (yg) {
+        pair_up(yp);
+        if (ok) {
+          T* dst = yg + (long long)ty * p.ldy + scol;
+          *reinterpret_cast<u32x4*>(dst) = u32x4{yp[0], yp[1], yp[2], yp[3]};
+          *reinterpret_cast<u32x4*>(dst + 16) = u32x4{yp[4], yp[5], yp[6], yp[7]};
+        }
+      }
+      if (ug) {
+        pair_up(up);
+        if (ok) {
+          T* dst = ug + (long long)ty * p.ldya + scol;
+          *reinterpret_cast<u32x4*>(dst) = u32x4{up[0], up[1], up[2], up[3]};
+          *reinterpret_cast<u32x4*>(dst + 16) = u32x4{up[4], up[5], up[6], up[7]};
+        }
+      }
+    }
+  }
+}
+
+template <int NTAPS>
+static void launch_ws(const ConvArgs& p, const void* zero_page, dim3 grid, size_t lds, int tpw, int buf_bytes,
+                      hipStream_t stream) {
+  (void)hipFuncSetAttribute((const void*)conv_ws_kernel<NTAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  conv_ws_kernel<NTAPS><<<grid, WS_NT, lds, stream>>>(p, (const __bf16*)zero_page, tpw, buf_bytes);
+}
+
 static int launch_conv1x1_dma(ConvArgs p, const void* zero_page, hipStream_t stream) {
   p.tiles_per_batch = (p.Tout + DMA_BM - 1) / DMA_BM;
   const int ntiles = p.tiles_per_batch * p.B;
@@ -654,14 +938,32 @@ static bool conv_dma_eligible(const smt_conv_desc* d) {
          d->out_stride == 1 && d->out_offset == 0 && d->t_y == d->t_out && d->zero_page != nullptr;
 }
 
-static int launch_conv_dma(ConvArgs p, const void* zero_page, hipStream_t stream) {
-  // Dilation classes (see the kernel) for same-size convs whose padding is a multiple of a large dilation,
-  // as long as a class still has enough rows to fill tiles.
+// Plan of the LDS-DMA family for one conv: dilation classes, then weight-stationary / 256-row / 128-row tiles.
+struct DmaPlan { bool ws; bool big; int buf_bytes; size_t lds; int tiles_per_wg; dim3 grid; };
+static bool plan_conv_dma(ConvArgs& p, DmaPlan& pl) {
+  // Dilation classes (see conv_gemm_dma_kernel) for same-size convs whose padding is a multiple of a large
+  // dilation, as long as a class still has enough rows to fill tiles.
   p.rs = 1;
   if (p.dil >= 8 && p.taps > 1 && p.pad % p.dil == 0 && p.Tin == p.Tout && p.Tout / p.dil >= 512) {
     p.rs = p.dil; p.pad /= p.dil; p.dil = 1;
   }
   const int tc_max = (p.Tout + p.rs - 1) / p.rs;
+  {  // weight-stationary persistent kernel: 128 input channels, odd tap counts 3..9, enough tiles per workgroup
+    static const bool no_ws = getenv("SMT_CONV_NO_WS") != nullptr;
+    const int rows_pad = (WS_BM + (p.taps - 1) * p.dil + 3) & ~3;
+    const int buf_bytes = (int)align_up((size_t)std::max(rows_pad * 256, WS_BM * (DMA_BN + 8) * 2), 1024);
+    const size_t lds = 2 * (size_t)buf_bytes + 2 * WS_EPI;
+    const int tpb = (tc_max + WS_BM - 1) / WS_BM;
+    const long long ntiles = (long long)tpb * p.B * p.rs;
+    if (!no_ws && p.Cin == 128 && p.taps >= 3 && p.taps <= 9 && (p.taps & 1) && lds <= 160 * 1024 && ntiles >= 256 * 4) {
+      p.tiles_per_batch = tpb;
+      const int nwg = 256;
+      pl.ws = true; pl.big = false; pl.buf_bytes = buf_bytes; pl.lds = lds;
+      pl.tiles_per_wg = (int)((ntiles + nwg - 1) / nwg);
+      pl.grid = dim3((unsigned)nwg, (unsigned)(p.Cout / DMA_BN));
+      return true;
+    }
+  }
   auto lds_for = [&](int bm) {
     const int rows_in = (bm - 1) + (p.taps - 1) * p.dil + 1;
     const int rows_pad = (rows_in + 3) & ~3;
@@ -669,19 +971,36 @@ static int launch_conv_dma(ConvArgs p, const void* zero_page, hipStream_t stream
     return a_bytes + (size_t)(p.taps > 1 ? 2 : 1) * DMA_BN * 256;   // one weight buffer suffices for 1x1
   };
   // 256-row tiles when they fit in LDS and there are enough rows to keep every CU busy
-  const bool big = p.taps > 1 && lds_for(256) <= 160 * 1024 && (long long)tc_max * p.B * p.rs >= 256LL * 256 * 2;
-  const int bm = big ? 256 : 128;
-  const size_t lds = lds_for(bm);
-  SMT_CHECK_ARG(lds <= 160 * 1024, "conv_gemm_dma: tile needs %zu B of LDS", lds);
+  pl.ws = false;
+  pl.big = p.taps > 1 && lds_for(256) <= 160 * 1024 && (long long)tc_max * p.B * p.rs >= 256LL * 256 * 2;
+  const int bm = pl.big ? 256 : 128;
+  pl.lds = lds_for(bm);
+  if (pl.lds > 160 * 1024) return false;
   p.tiles_per_batch = (tc_max + bm - 1) / bm;
   const int ntiles = p.tiles_per_batch * p.B * p.rs;
-  dim3 grid((unsigned)(8 * ((ntiles + 7) / 8)), (unsigned)(p.Cout / DMA_BN));
-  if (big) {
+  pl.grid = dim3((unsigned)(8 * ((ntiles + 7) / 8)), (unsigned)(p.Cout / DMA_BN));
+  return true;
+}
+
+static int launch_conv_dma(ConvArgs p, const void* zero_page, hipStream_t stream) {
+  DmaPlan pl;
+  SMT_CHECK_ARG(plan_conv_dma(p, pl), "conv_gemm_dma: tile needs %zu B of LDS", pl.lds);
+  if (pl.ws) {
+    switch (p.taps) {
+      case 3: launch_ws<3>(p, zero_page, pl.grid, pl.lds, pl.tiles_per_wg, pl.buf_bytes, stream); break;
+      case 5: launch_ws<5>(p, zero_page, pl.grid, pl.lds, pl.tiles_per_wg, pl.buf_bytes, stream); break;
+      case 7: launch_ws<7>(p, zero_page, pl.grid, pl.lds, pl.tiles_per_wg, pl.buf_bytes, stream); break;
+      default: launch_ws<9>(p, zero_page, pl.grid, pl.lds, pl.tiles_per_wg, pl.buf_bytes, stream); break;
+    }
+    SMT_CHECK_LAUNCH("conv_ws");
+    return 0;
+  }
+  if (pl.big) {
     (void)hipFuncSetAttribute((const void*)conv_gemm_dma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    conv_gemm_dma_kernel<4><<<grid, DMA_NT, lds, stream>>>(p, (const __bf16*)zero_page);
+    conv_gemm_dma_kernel<4><<<pl.grid, DMA_NT, pl.lds, stream>>>(p, (const __bf16*)zero_page);
   } else {
     (void)hipFuncSetAttribute((const void*)conv_gemm_dma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    conv_gemm_dma_kernel<2><<<grid, DMA_NT, lds, stream>>>(p, (const __bf16*)zero_page);
+    conv_gemm_dma_kernel<2><<<pl.grid, DMA_NT, pl.lds, stream>>>(p, (const __bf16*)zero_page);
   }
   SMT_CHECK_LAUNCH("conv_gemm_dma");
   return 0;
@@ -767,6 +1086,34 @@ extern "C" int smt_pack_weight(const float* src, void* dst, int dtype, int n_out
   return 0;
 }
 
+static void conv_args_from_desc(const smt_conv_desc* d, ConvArgs& p) {
+  p.x = d->x; p.w = d->w; p.bias = d->bias; p.y = d->y; p.res = d->res; p.gate_h = d->act_grad_src;
+  p.lens_in = d->lens_in; p.lens_out = d->lens_out;
+  p.x_bs = d->bs_x; p.y_bs = d->bs_y; p.res_bs = d->bs_res; p.gh_bs = d->bs_act;
+  p.ldx = d->ld_x; p.ldy = d->ld_y; p.ldr = d->ld_res; p.ldgh = d->ld_act;
+  p.B = d->batch; p.Tin = d->t_in; p.Tout = d->t_out; p.Cin = d->c_in; p.Cout = d->c_out;
+  p.taps = d->taps; p.stride = d->stride; p.dil = d->dilation; p.pad = d->padding;
+  p.out_stride = d->out_stride; p.out_offset = d->out_offset; p.Ty = d->t_y;
+  p.y_act = d->y_act; p.ya_bs = d->bs_yact; p.ldya = d->ld_yact;
+  p.act_out = d->act_out; p.epi_act = d->act_grad;
+  for (int i = 0; i < 8; ++i) p.drop_keys[i] = d->drop_keys[i];
+  p.site_width = d->site_width; p.drop_thresh16 = d->drop_thresh16; p.drop_scale = d->drop_scale;
+  p.tiles_per_batch = 0;
+  p.rs = 1;
+  { static int dbg = getenv("SMT_CONV_DBG") ? atoi(getenv("SMT_CONV_DBG")) : 0; p.dbg = dbg; }
+}
+
+enum ConvKernelKind { K_GENERIC, K_1X1, K_DMA, K_WS };
+// the one dispatch rule (smt_conv1d_ntc and smt_conv1d_kernel_name both use it)
+static ConvKernelKind pick_kernel(const smt_conv_desc* d, const ConvArgs& p0) {
+  if (!conv_dma_eligible(d)) return K_GENERIC;
+  if (d->taps == 1 && d->c_in == 128) return K_1X1;
+  ConvArgs p = p0;
+  DmaPlan pl;
+  if (!plan_conv_dma(p, pl)) return K_GENERIC;
+  return pl.ws ? K_WS : K_DMA;
+}
+
 extern "C" int smt_conv1d_ntc(const smt_conv_desc* d, smt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SMT_CHECK_ARG(d && d->x && d->w && (d->y || d->y_act), "smt_conv1d_ntc: null pointer");
@@ -791,26 +1138,25 @@ extern "C" int smt_conv1d_ntc(const smt_conv_desc* d, smt_stream_t stream_) {
                 "smt_conv1d_ntc: act_out needs y_act and 1..8 sites of site_width channels");
   if (d->batch == 0 || d->t_out == 0) return 0;
   ConvArgs p;
-  p.x = d->x; p.w = d->w; p.bias = d->bias; p.y = d->y; p.res = d->res; p.gate_h = d->act_grad_src;
-  p.lens_in = d->lens_in; p.lens_out = d->lens_out;
-  p.x_bs = d->bs_x; p.y_bs = d->bs_y; p.res_bs = d->bs_res; p.gh_bs = d->bs_act;
-  p.ldx = d->ld_x; p.ldy = d->ld_y; p.ldr = d->ld_res; p.ldgh = d->ld_act;
-  p.B = d->batch; p.Tin = d->t_in; p.Tout = d->t_out; p.Cin = d->c_in; p.Cout = d->c_out;
-  p.taps = d->taps; p.stride = d->stride; p.dil = d->dilation; p.pad = d->padding;
-  p.out_stride = d->out_stride; p.out_offset = d->out_offset; p.Ty = d->t_y;
-  p.y_act = d->y_act; p.ya_bs = d->bs_yact; p.ldya = d->ld_yact;
-  p.act_out = d->act_out; p.epi_act = d->act_grad;
-  for (int i = 0; i < 8; ++i) p.drop_keys[i] = d->drop_keys[i];
-  p.site_width = d->site_width; p.drop_thresh16 = d->drop_thresh16; p.drop_scale = d->drop_scale;
-  p.tiles_per_batch = 0;
-  p.rs = 1;
-  { static int dbg = getenv("SMT_CONV_DBG") ? atoi(getenv("SMT_CONV_DBG")) : 0; p.dbg = dbg; }
-  if (conv_dma_eligible(d) && d->taps == 1 && d->c_in == 128) return launch_conv1x1_dma(p, d->zero_page, stream);
-  if (conv_dma_eligible(d)) {
-    const int rows_in = 127 + (d->taps - 1) * d->dilation + 1;
-    if (((rows_in + 3) & ~3) * 256 + 2 * 128 * 256 <= 160 * 1024) return launch_conv_dma(p, d->zero_page, stream);
+  conv_args_from_desc(d, p);
+  switch (pick_kernel(d, p)) {
+    case K_1X1: return launch_conv1x1_dma(p, d->zero_page, stream);
+    case K_DMA: case K_WS: return launch_conv_dma(p, d->zero_page, stream);
+    default: break;
   }
   SMT_CHECK_ARG(!d->w_swizzled, "smt_conv1d_ntc: swizzled weights need the LDS-DMA path (bf16, stride 1, channels %% 128)");
   if (d->dtype == SMT_BF16) return launch_conv_gemm<__bf16>(p, stream);
   return launch_conv_gemm<float>(p, stream);
+}
+
+extern "C" const char* smt_conv1d_kernel_name(const smt_conv_desc* d) {
+  if (!d) return "";
+  ConvArgs p;
+  conv_args_from_desc(d, p);
+  switch (pick_kernel(d, p)) {
+    case K_1X1: return "conv1x1_dma";
+    case K_WS: return "conv_ws";
+    case K_DMA: return "conv_gemm_dma";
+    default: return "conv_gemm";
+  }
 }

@@ -122,10 +122,8 @@ def _tag(desc):
 
 
 def _kernel_of(desc):
-    """Which kernel smt_conv1d_ntc dispatches to (mirrors the rule in csrc/conv.hip)."""
-    if desc.w_swizzled:
-        return "conv1x1_dma" if (desc.taps == 1 and desc.c_in == 128) else "conv_gemm_dma"
-    return "conv_gemm"
+    """Which kernel smt_conv1d_ntc dispatches to (asked of the library: one dispatch rule, csrc/conv.hip)."""
+    return N.lib().smt_conv1d_kernel_name(ctypes.byref(desc)).decode()
 
 
 def _launch(desc, name, flops=0.0, nbytes=0.0):

@@ -275,3 +275,44 @@ def test_lds_dma_conv_kernel_matches_generic_kernel(k, dil):
         outs.append((y, u))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert outs[0][0].float().abs().sum() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,dil", [(3, 1), (5, 3), (7, 9), (9, 27)])
+@pytest.mark.parametrize("epi", ["plain", "res+actgrad+actout"])
+def test_weight_stationary_conv_kernel_matches_generic_kernel(k, dil, epi):
+    """The persistent weight-stationary kernel (weights in registers, double-buffered LDS-DMA activation tiles,
+    dilation classes for dil >= 8) against the register-staged generic kernel on enough rows for it to be
+    dispatched: same MFMA and accumulation order -> bit-identical outputs, ragged lens included."""
+    from smt_amd import convops as C
+    g = torch.Generator(device="cuda").manual_seed(100 + k)
+    b, t, c = 3, 50021, 128
+    big = torch.randn(b, t, 256, device="cuda", generator=g).to(torch.bfloat16)
+    x = big[:, :, 128:256]                                   # channel slice: row pitch 256
+    w = torch.randn(c, c, k, device="cuda", generator=g) / (c * k) ** 0.5
+    bias = torch.randn(c, device="cuda", generator=g)
+    res = torch.randn(b, t, c, device="cuda", generator=g).to(torch.bfloat16)
+    u_src = torch.relu(torch.randn(b, t, c, device="cuda", generator=g)).to(torch.bfloat16)
+    lens = torch.tensor([t, 33333, 1], device="cuda", dtype=torch.int32)
+    pad = (k - 1) * dil // 2
+    outs, names = [], []
+    for dma in (False, True):
+        y = torch.zeros(b, t, c, device="cuda", dtype=torch.bfloat16)
+        u = torch.zeros_like(y)
+        wp = C._pack_fwd(w, torch.bfloat16, dma)
+        d = C._base_desc(x, y, lens, c, c, k, 1, dil, pad, t)
+        d.w, d.bias = C._p(wp), C._p(bias)
+        if dma:
+            C._use_dma(d, wp)
+        d.lens_out = C._p(lens)
+        if epi != "plain":
+            d.res, d.bs_res, d.ld_res = C._geom(res)
+            C._set_act_grad(d, u_src, 1.111)
+            C._set_act_out(d, u, [C.dropout_key(3, 5)], 6554, 1.0 / 0.9, c)
+        names.append(C._kernel_of(d))
+        C._launch(d, "t")
+        torch.cuda.synchronize()
+        outs.append((y, u))
+    assert names == ["conv_gemm", "conv_ws"]
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][0].float().abs().sum() > 0

@@ -1,0 +1,12 @@
+#!/bin/bash
+# Ablation of conv_gemm_dma_kernel on the GPU box: rebuilds conv.hip with -DSMT_ABL=<mask> and times the
+# k=9 / dilation 27 forward conv.  Masks: 1 no activation DMA, 2 no weight re-staging, 4 no MFMA,
+# 8 no activation fragment reads, 16 no weight fragment reads.  Results are NOT numerically valid.
+set -e
+cd "$(dirname "$0")/../speech-masters-thesis_amd/csrc"
+for m in ${MASKS:-0 4 32 36}; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=on -DSMT_ABL=$m -c conv.hip -o build/conv.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../smt_amd/libsmt_hip.so build/*.o
+  echo "== SMT_ABL=$m (conv_ws: 4 no MFMA loop, 32 no epilogue)"
+  python ../../tools/bench_dma.py 2>&1 | grep "dma=1"
+done

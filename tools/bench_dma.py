@@ -15,7 +15,7 @@ dt = torch.bfloat16
 x = torch.randn(B, T, 128, device="cuda").to(dt); y = torch.empty_like(x); res = torch.randn(B, T, 128, device="cuda").to(dt)
 u = torch.empty_like(x)
 bias = torch.randn(128, device="cuda")
-for (k, dil) in [(1, 1), (3, 1), (5, 3), (9, 27)]:
+for (k, dil) in [(1, 1), (3, 1), (5, 3), (7, 9), (9, 27)]:
     w = torch.randn(128, 128, k, device="cuda") / (128 * k) ** 0.5
     pad = (k - 1) * dil // 2
     for dma in (False, True):

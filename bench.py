@@ -40,6 +40,8 @@ def parse():
     p.add_argument("--model", type=str, default="vqvae_k1024")
     p.add_argument("--clip_len", type=int, default=CLIP_LEN)
     p.add_argument("--no_cpu_baseline", action="store_true")
+    p.add_argument("--no_kernel_events", action="store_true",
+                   help="do not bracket kernels with HIP events in the timed region (no roofline objects)")
     p.add_argument("--cpu_clip_len", type=int, default=CLIP_LEN)
     return p.parse_args()
 
@@ -133,13 +135,14 @@ def main():
         torch.cuda.synchronize()
         note(f"warm-up step {i} done")
     profiler.reset()
-    profiler.enable(True)
+    profiler.enable(not args.no_kernel_events)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss_dict, _ = step(args.warmup + i)
+    host_elapsed = time.perf_counter() - t0     # all launches enqueued (the host runs ahead of the GPU)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -206,6 +209,7 @@ def main():
             "unit": "utterances/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "host_enqueue_ms_per_step": host_elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": m.get("compute_dtype", "fp32"), "data": "synthetic",
             "config": {"workload": f"configs[1]: models/vqvae codebook={m.l_bins}, batch={args.batch}/GPU, "

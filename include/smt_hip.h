@@ -141,6 +141,15 @@ int smt_conv1d_wgrad(const smt_conv_desc* desc, float* dweight, int64_t stride_o
                      int64_t stride_tap, const int* tap_map, float* dbias, void* workspace,
                      size_t workspace_bytes, smt_stream_t stream);
 
+/* Fused backward of a bf16 128 -> 128 1x1 convolution whose forward input was u = relu(dropout(h)) (K3 of
+ * GatedHiFiBlock, resnet.py:218-227): one pass over dy and u yields the masked data gradient AND the weight / bias
+ * gradients.  `desc` is the 1x1 DATA-GRADIENT descriptor as for smt_conv1d_ntc (x = dy, y = dx, w = weights packed
+ * [ci][co] with swizzle = 1, act_grad = 1 with act_grad_src = u, drop_scale, zero_page; no bias / res / act_out);
+ * dweight[co*stride_out + ci*stride_in] = sum_t dy[t,co] * u[t,ci], dbias[co] = sum_t dy[t,co] (fp32, may be NULL). */
+size_t smt_conv1x1_bwd_workspace_bytes(const smt_conv_desc* desc);
+int smt_conv1x1_bwd(const smt_conv_desc* desc, float* dweight, int64_t stride_out, int64_t stride_in, float* dbias,
+                    void* workspace, size_t workspace_bytes, smt_stream_t stream);
+
 /* sum_d tanh(t_d) * softmax_d(s_d) over `depth` branches laid side by side along the channel axis
  * (z[.., d*2w + c] = t_d, z[.., d*2w + w + c] = s_d) -- GatedHiFiBlock.forward, resnet.py:229-237. */
 int smt_gate_mix_fwd(const void* z, void* g, int dtype, int64_t rows, int width, int depth, int ld_z, int ld_g,

@@ -664,12 +664,6 @@ __global__ __launch_bounds__(DMA_NT) void conv1x1_dma_kernel(ConvArgs p, const _
 constexpr int WS_AGPR_TAPS = 7;   // taps whose weights are pinned to AccVGPRs (7 x 32 = 224 of 256)
 constexpr int WS_BM = 128, WS_NT = 256, WS_EPI = 128 * 256;   // rows per tile, threads, epilogue-operand tile bytes
 
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-  bf16x2 v = {(__bf16)lo, (__bf16)hi};
-  return __builtin_bit_cast(unsigned, v);
-}
-
 template <int NTAPS>
 __global__ __launch_bounds__(WS_NT) void conv_ws_kernel(ConvArgs p, const __bf16* __restrict__ zero_page,
                                                         int tiles_per_wg, int buf_bytes) {
@@ -850,14 +844,14 @@ __global__ __launch_bounds__(WS_NT) void conv_ws_kernel(ConvArgs p, const __bf16
         for (int k = 0; k < 4; ++k) o[k] = (float)(T)(acc[i][4 * g + k] + bval[4 * g + k]);
         const int eoff = row * 64 + ((g ^ swz) << 4) + 8 * hh;
         if (p.epi_act) {
-          Vec<T, 4> uv = *reinterpret_cast<const Vec<T, 4>*>(lds_act + eoff);
+          const bf16x4 uv = *reinterpret_cast<const bf16x4*>(lds_act + eoff);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) o[k] = ((float)uv.v[k] != 0.f) ? o[k] * p.drop_scale : 0.f;
+          for (int k = 0; k < 4; ++k) o[k] = ((float)uv[k] != 0.f) ? o[k] * p.drop_scale : 0.f;
         }
         if (p.res) {
-          Vec<T, 4> rv = *reinterpret_cast<const Vec<T, 4>*>(lds_res + eoff);
+          const bf16x4 rv = *reinterpret_cast<const bf16x4*>(lds_res + eoff);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) o[k] = fmaf(o[k], keep_row, (float)rv.v[k]);
+          for (int k = 0; k < 4; ++k) o[k] = fmaf(o[k], keep_row, (float)rv[k]);
         } else {
 #pragma unroll
           for (int k = 0; k < 4; ++k) o[k] *= keep_row;

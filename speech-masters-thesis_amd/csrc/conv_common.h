@@ -5,6 +5,7 @@
 namespace smt {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 // ---- counter-based dropout (spec: include/smt_hip.h "dropout") -------------------------------
@@ -34,6 +35,24 @@ template <> struct Tr<float> {
 };
 
 template <typename T, int EPV> struct Vec { T v[EPV]; } __attribute__((aligned(16)));
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
+}
+
+// LDS-DMA: one wave-instruction copies 64 x 16 B (per-lane global source) to 1 KiB of LDS at a wave-uniform base
+__device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst_wave_base) {
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,
+                                   (void __attribute__((address_space(3)))*)lds_dst_wave_base, 16, 0, 0);
+}
+
+// Fixed-order reduction of weight-gradient partial slabs (conv_wgrad.hip): slab[chunk][blk = co/64 * nblk_ci + ci/cib]
+// [plane = tap | bias][64 co][cib ci] -> dw[co*so + ci*si + jmap[tap]*sj], db[co] (column 0 of the bias plane).
+int launch_wgrad_reduce(const float* slab, float* dw, float* db, int n_chunks, int nblk_co, int nblk_ci, int taps,
+                        int c_in, int c_out, int cib, long long so, long long si, long long sj, const int* jmap,
+                        hipStream_t stream);
 
 
 }  // namespace smt

@@ -20,8 +20,6 @@
 
 namespace smt {
 
-constexpr int WG_MAX_TAPS = 9;
-
 struct WgradArgs {
   const void* x; const void* dy; float* slab;
   const int* lens_in;
@@ -244,6 +242,11 @@ __device__ __forceinline__ bf16x8 frag_tr_swz(const unsigned char* tile, int row
   return __builtin_bit_cast(bf16x8, v);
 }
 
+#ifndef SMT_WABL
+#define SMT_WABL 0   // ablation build switches (tools/ablate_wgrad.sh): 1 stage once, 2 no fragment reads, 4 no MFMA
+#endif
+constexpr int WABL = SMT_WABL;
+
 template <int NT>
 __global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(WgradArgs p, const __bf16* __restrict__ zero_page) {
   typedef __bf16 T;
@@ -342,16 +345,19 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(WgradArgs p, const 
     const int buf = it & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                       // tile `it` has landed for every wave; the other buffer is free
-    if (t0 + R < t_end) stage(t0 + R, buf ^ 1);
+    if (t0 + R < t_end && !((WABL & 1) && it > 0)) stage(t0 + R, buf ^ 1);
     const unsigned char* dyt = smem + (size_t)buf * buf_bytes + dyoff;
     const unsigned char* xbase = smem + (size_t)buf * buf_bytes + DY_BYTES;
+    bf16x8 a0, b0;
+    if (WABL & 2) { a0 = tr2(dyt, 0, 4 * DYB); b0 = tr2(xbase + xoff[0], 0, 4 * XB); }
 #pragma unroll
     for (int k0 = 0; k0 < R; k0 += 16) {
-      bf16x8 a = tr2(dyt, k0 * DYB, 4 * DYB);
+      bf16x8 a = (WABL & 2) ? a0 : tr2(dyt, k0 * DYB, 4 * DYB);
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         if (j < ntaps) {
-          bf16x8 bfrag = tr2(xbase + xoff[j], k0 * XB, 4 * XB);
+          bf16x8 bfrag = (WABL & 2) ? b0 : tr2(xbase + xoff[j], k0 * XB, 4 * XB);
+          if (WABL & 4) { asm volatile("" :: "v"(a), "v"(bfrag)); continue; }
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag, acc[j], 0, 0, 0);
         } else if (j == ntaps && bias_plane) {
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ones, acc[j], 0, 0, 0);
@@ -445,6 +451,21 @@ static void wgrad_plan(const smt_conv_desc* d, int* rows_per_chunk, int* chunks_
   *rows_per_chunk = (int)rows;
   *chunks_per_batch = (int)((tc + rows - 1) / rows);
   *planes = d->taps + 1;
+}
+
+int launch_wgrad_reduce(const float* slab, float* dw, float* db, int n_chunks, int nblk_co, int nblk_ci, int taps,
+                        int c_in, int c_out, int cib, long long so, long long si, long long sj, const int* jmap,
+                        hipStream_t stream) {
+  WreduceArgs r;
+  r.slab = slab; r.dw = dw; r.db = db;
+  r.n_chunks = n_chunks; r.nblk = nblk_co * nblk_ci; r.nblk_ci = nblk_ci; r.planes = taps + 1; r.taps = taps;
+  r.Cin = c_in; r.Cout = c_out; r.with_bias = db ? 1 : 0; r.cib = cib;
+  r.so = so; r.si = si; r.sj = sj;
+  for (int t = 0; t < taps; ++t) r.jmap[t] = jmap[t];
+  const long long total = (long long)r.planes * c_out * c_in;
+  conv_wgrad_reduce_kernel<<<(unsigned)((total + 31) / 32), 256, 0, stream>>>(r);
+  SMT_CHECK_LAUNCH("conv_wgrad_reduce");
+  return 0;
 }
 
 }  // namespace smt
@@ -557,17 +578,9 @@ static int wgrad_group(const smt_conv_desc* d, float* dweight, int64_t stride_ou
                       : launch_wgrad<float, 64, false>(a, grid, lds, planes, stream);
     if (rc) return rc;
   }
-  WreduceArgs r;
-  r.slab = (const float*)workspace; r.dw = dweight; r.db = dbias;
-  r.n_chunks = d->batch * rs * cpb; r.nblk = nco * nci; r.nblk_ci = nci; r.planes = planes; r.taps = d->taps;
-  r.Cin = d->c_in; r.Cout = d->c_out; r.with_bias = dbias ? 1 : 0; r.cib = cib;
-  r.so = stride_out; r.si = stride_in; r.sj = stride_tap;
-  for (int t = 0; t < d->taps; ++t) r.jmap[t] = tap_map[t];
-  if (d->batch == 0 || d->t_out == 0) r.n_chunks = 0;
-  long long total = (long long)planes * d->c_out * d->c_in;
-  conv_wgrad_reduce_kernel<<<(unsigned)((total + 31) / 32), 256, 0, stream>>>(r);
-  SMT_CHECK_LAUNCH("conv_wgrad_reduce");
-  return 0;
+  const int n_chunks = (d->batch == 0 || d->t_out == 0) ? 0 : d->batch * rs * cpb;
+  return launch_wgrad_reduce((const float*)workspace, dweight, dbias, n_chunks, nco, nci, d->taps, d->c_in, d->c_out,
+                             cib, stride_out, stride_in, stride_tap, tap_map, stream);
 }
 
 extern "C" int smt_conv1d_wgrad(const smt_conv_desc* d, float* dweight, int64_t stride_out, int64_t stride_in,

@@ -185,6 +185,19 @@ def _wgrad(desc, dweight, s_out, s_in, s_tap, tap_map, dbias):
                                      ws.numel(), N.stream_ptr()), "smt_conv1d_wgrad")
 
 
+def _conv1x1_bwd(desc, dweight, s_out, s_in, dbias):
+    """Fused data + weight gradient of a 128 -> 128 1x1 conv behind relu+dropout (smt_conv1x1_bwd): `desc` is the
+    data-gradient descriptor with act_grad set; one pass over dy and u instead of two."""
+    lib = N.lib()
+    ws_bytes = lib.smt_conv1x1_bwd_workspace_bytes(ctypes.byref(desc))
+    ws = N.workspace.get(ws_bytes, dweight.device)
+    rows = float(desc.batch) * desc.t_out
+    name = "conv1x1_bwd" + ("_" + _tag(desc) if profiler.DETAIL else "")
+    with profiler.region(name, flops=2 * _conv_flops(desc), nbytes=rows * 3 * desc.c_in * 2, bound="hbm", dtype="bf16"):
+        N.check(lib.smt_conv1x1_bwd(ctypes.byref(desc), _p(dweight), s_out, s_in, _p(dbias), _p(ws), ws.numel(),
+                                    N.stream_ptr()), "smt_conv1x1_bwd")
+
+
 def _set_act_out(d, u, keys, thresh, scale, site_width):
     d.act_out, d.site_width = 1, site_width
     d.y_act, d.bs_yact, d.ld_yact = _geom(u)
@@ -560,10 +573,14 @@ class _GatedHiFi(torch.autograd.Function):
             if dma:
                 _use_dma(d, wb3)
             _set_act_grad(d, u2_d, scale)
-            _launch(d, "conv_dgrad", _conv_flops(d), _conv_bytes(d, x.element_size()))
             grads[6 * dd + 4], grads[6 * dd + 5] = torch.empty_like(w3), f32(b3.shape)
-            _wgrad(_base_desc(u2_d, dz_d, None, c2, c2, 1, 1, 1, 0, t), grads[6 * dd + 4], c2, 1, 1, [0],
-                   grads[6 * dd + 5])
+            if dma and c2 == 128:
+                # data gradient and weight gradient read the same two operands (dz_d, u2_d): one fused pass
+                _conv1x1_bwd(d, grads[6 * dd + 4], c2, 1, grads[6 * dd + 5])
+            else:
+                _launch(d, "conv_dgrad", _conv_flops(d), _conv_bytes(d, x.element_size()))
+                _wgrad(_base_desc(u2_d, dz_d, None, c2, c2, 1, 1, 1, 0, t), grads[6 * dd + 4], c2, 1, 1, [0],
+                       grads[6 * dd + 5])
             # K2: dh1_d = (dh2 * W2^T) * act'(u1) + dz_d;  dW2 = u1^T dh2
             wb2 = _pack_bwd(w2, dt, dma)
             d = _dgrad_stride1(dh2, wb2, dh1[:, :, sl], k, dil, pad)

@@ -316,3 +316,44 @@ def test_weight_stationary_conv_kernel_matches_generic_kernel(k, dil, epi):
     assert names == ["conv_gemm", "conv_ws"]
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert outs[0][0].float().abs().sum() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,t", [(3, 700), (2, 33000), (1, 1)])
+def test_fused_1x1_backward_matches_separate_kernels(b, t):
+    """smt_conv1x1_bwd (one pass over dy and u) against the data-gradient conv + the weight-gradient kernel it
+    replaces: the masked data gradient is bit-identical (same MFMA, same order, same rounding), the fp32 weight
+    and bias gradients agree to summation-order round-off and match a float64 reference."""
+    from smt_amd import convops as C
+    g = torch.Generator(device="cuda").manual_seed(7 * b + t)
+    c = 128
+    big = torch.randn(b, t, 512, device="cuda", generator=g).to(torch.bfloat16)
+    dz = big[:, :, 256:384]                                  # channel slices of wider tensors: row pitch 512
+    u_big = torch.relu(torch.randn(b, t, 512, device="cuda", generator=g)).to(torch.bfloat16)
+    u2 = u_big[:, :, 128:256]
+    w = torch.randn(c, c, 1, device="cuda", generator=g) / c ** 0.5
+    scale = 1.0 / 0.9
+    wb = C._pack_bwd(w, torch.bfloat16, True)
+
+    def desc(dx):
+        d = C._dgrad_stride1(dz, wb, dx, 1, 1, 0)
+        C._use_dma(d, wb)
+        C._set_act_grad(d, u2, scale)
+        return d
+
+    dx_ref = torch.zeros(b, t, c, device="cuda", dtype=torch.bfloat16)
+    C._launch(desc(dx_ref), "t")
+    dw_ref, db_ref = torch.empty_like(w), torch.empty(c, device="cuda")
+    C._wgrad(C._base_desc(u2, dz, None, c, c, 1, 1, 1, 0, t), dw_ref, c, 1, 1, [0], db_ref)
+
+    dx = torch.zeros_like(dx_ref)
+    dw, db = torch.empty_like(w), torch.empty(c, device="cuda")
+    C._conv1x1_bwd(desc(dx), dw, c, 1, db)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx_ref)
+    dw64 = torch.einsum("bto,bti->oi", dz.double(), u2.double())
+    db64 = dz.double().sum((0, 1))
+    tol = 1e-5 * float(dw64.abs().max()) + 1e-6
+    assert float((dw[:, :, 0].double() - dw64).abs().max()) <= 20 * tol
+    assert float((dw - dw_ref).abs().max()) <= 20 * tol
+    assert float((db.double() - db64).abs().max()) <= 1e-5 * float(db64.abs().max()) + 1e-4

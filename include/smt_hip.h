@@ -125,10 +125,19 @@ typedef struct smt_conv_desc {
   const int* lens_in; const int* lens_out;
   int w_swizzled;                  /* w was packed with swizzle = 1: enables the LDS-DMA kernel */
   const void* zero_page;           /* >= 256 zero bytes in device memory (source of out-of-range rows), or NULL */
+  /* Optional second 1x1 term folded into the same output (bf16 1x1 LDS-DMA path only, c_in == 128, c_in2 == 64):
+   *   y += bias2[co] + sum_ci2 x2[b, t, ci2] * w2[co][ci2]
+   * GatedHiFiBlock adds the branch input h1 = K1(x) + b1 to K3's output (resnet.py:226); K1 being linear, the
+   * residual can be recomputed from x inside K3 instead of being written and read back as a 2w-wide tensor. */
+  const void* x2; const void* w2;  /* x2 [B, t, c_in2] (pitch ld_x2, batch stride bs_x2); w2 [c_out][c_in2] packed, swizzle 0 */
+  const float* bias2;
+  const int* lens_in2;             /* rows >= lens_in2[b] of x2 read as 0 (lens_in applies to x only), or NULL */
+  int c_in2, ld_x2;
+  int64_t bs_x2;
 } smt_conv_desc;
 int smt_conv1d_ntc(const smt_conv_desc* desc, smt_stream_t stream);
 /* Name of the kernel smt_conv1d_ntc dispatches this descriptor to ("conv_gemm", "conv_gemm_dma", "conv_ws",
- * "conv1x1_dma"): for profilers and tests; no device work. */
+ * "conv1x1_dma", "conv1x1_fold"): for profilers and tests; no device work. */
 const char* smt_conv1d_kernel_name(const smt_conv_desc* desc);
 
 /* Weight (+ bias) gradient of the same convolution:

@@ -36,6 +36,7 @@ struct ConvArgs {
   unsigned drop_keys[8]; int site_width; unsigned drop_thresh16; float drop_scale;
   int tiles_per_batch;
   int rs;   // row stride of the dilation-class decomposition (LDS-DMA kernel), 1 = off
+  const void* x2; const void* w2; const float* bias2; const int* lens_in2; long long x2_bs; int ldx2;   // folded second 1x1 term (conv1x1_fold)
   int dbg;  // ablation switches (SMT_CONV_DBG): 1 no A loads, 2 no W loads, 4 no MFMA, 8 no stores
 };
 
@@ -912,6 +913,155 @@ static void launch_ws(const ConvArgs& p, const void* zero_page, dim3 grid, size_
   conv_ws_kernel<NTAPS><<<grid, WS_NT, lds, stream>>>(p, (const __bf16*)zero_page, tpw, buf_bytes);
 }
 
+// ------------------------------------------------------------------------------------------------
+// 1x1 conv with a folded second 1x1 term (bf16, C_in == 128, C_in2 == 64):
+//   y = W u + b  +  W2 x2 + b2
+// K3 of GatedHiFiBlock adds the branch input h1 = K1(x) + b1 (resnet.py:226).  K1 is linear, so the residual is
+// recomputed here from the 64-channel block input instead of being written by K1 and read back as a 128-channel
+// tensor: per row 384 B in / 256 B out instead of 512 B in / 256 B out here and 256 B less written by K1.
+// Same structure as conv1x1_bwd_kernel: persistent workgroups, both operand tiles through an LDS-DMA double
+// buffer, transposed MFMA tiles (A = weights in registers, B = rows) stored straight from registers.
+constexpr int FO_ROWS = 128, FO_NT = 512, FO_U = FO_ROWS * 256, FO_X = FO_ROWS * 128, FO_STAGE = FO_U + FO_X;
+
+__global__ __launch_bounds__(FO_NT) void conv1x1_fold_kernel(ConvArgs p, const __bf16* __restrict__ zero_page,
+                                                              int tiles_per_wg) {
+  typedef __bf16 T;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // 2 x [u tile 32 KiB | x2 tile 16 KiB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;          // rows 64 wm.., output channels n0 + 32 wn..
+  const int r = lane & 31, hh = lane >> 5;
+  const int n0 = blockIdx.y * 128;
+
+  const int ntiles = p.tiles_per_batch * p.B;
+  const int nwg = gridDim.x;
+  const int wg = (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3);
+  const int tile_begin = wg * tiles_per_wg;
+  const int tile_end = min(ntiles, tile_begin + tiles_per_wg);
+  if (tile_begin >= tile_end) return;
+
+  bf16x8 wfrag[8], w2frag[4];
+  {
+    const int co = n0 + wn * 32 + r;
+    const unsigned char* wrow = reinterpret_cast<const unsigned char*>(p.w) + (size_t)co * 256;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) wfrag[kk] = *reinterpret_cast<const bf16x8*>(wrow + (((2 * kk + hh) ^ (co & 15)) << 4));
+    const unsigned char* w2row = reinterpret_cast<const unsigned char*>(p.w2) + (size_t)co * 128;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) w2frag[kk] = *reinterpret_cast<const bf16x8*>(w2row + ((2 * kk + hh) << 4));
+  }
+  // accumulator element 4g + k of a lane = output channel col0 + 8g + k
+  const int col0 = n0 + wn * 32 + 4 * hh;
+  float bval[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int c = col0 + 8 * (e >> 2) + (e & 3);
+    bval[e] = (p.bias ? p.bias[c] : 0.f) + (p.bias2 ? p.bias2[c] : 0.f);
+  }
+
+  auto stage = [&](int tile, int buf) {
+    const int b = tile / p.tiles_per_batch;
+    const int t0 = (tile - b * p.tiles_per_batch) * FO_ROWS;
+    const T* ug = reinterpret_cast<const T*>(p.x) + (long long)b * p.x_bs;
+    const T* xg = reinterpret_cast<const T*>(p.x2) + (long long)b * p.x2_bs;
+    const int len_in = p.lens_in ? min(p.lens_in[b], p.Tin) : p.Tin;
+    const int len_in2 = p.lens_in2 ? min(p.lens_in2[b], p.Tin) : p.Tin;
+    unsigned char* base = smem + (size_t)buf * FO_STAGE;
+#pragma unroll
+    for (int q = 0; q < (FO_ROWS / 4) / (FO_NT / 64); ++q) {     // u: 4 rows x 16 chunks per instruction
+      const int g = wave + (FO_NT / 64) * q;
+      const int row = 4 * g + (lane >> 4), pos = lane & 15;
+      const int t = t0 + row;
+      lds_dma16(t < len_in ? ug + (long long)t * p.ldx + ((pos ^ (row & 15)) * 8) : zero_page + pos * 8, base + g * 1024);
+    }
+#pragma unroll
+    for (int q = 0; q < (FO_ROWS / 8) / (FO_NT / 64); ++q) {     // x2: 8 rows x 8 chunks per instruction
+      const int g = wave + (FO_NT / 64) * q;
+      const int row = 8 * g + (lane >> 3), pos = lane & 7;
+      const int t = t0 + row;
+      // 128-byte rows: two rows share a 256-byte bank window, chunk c of row n sits at c ^ ((n >> 1) & 7)
+      lds_dma16(t < len_in2 ? xg + (long long)t * p.ldx2 + ((pos ^ ((row >> 1) & 7)) * 8) : zero_page + pos * 8,
+                base + FO_U + g * 1024);
+    }
+  };
+
+  stage(tile_begin, 0);
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    const int buf = (tile - tile_begin) & 1;
+    const int b = tile / p.tiles_per_batch;
+    const int t0 = (tile - b * p.tiles_per_batch) * FO_ROWS;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile has landed
+    __syncthreads();                                    // ... for every wave; the other buffer is free again
+    if (tile + 1 < tile_end) stage(tile + 1, buf ^ 1);
+    const unsigned char* ut = smem + (size_t)buf * FO_STAGE;
+    const unsigned char* xt = ut + FO_U;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = wm * 64 + 32 * i + r;
+        bf16x8 bv = *reinterpret_cast<const bf16x8*>(ut + row * 256 + (((2 * kk + hh) ^ (row & 15)) << 4));
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[kk], bv, acc[i], 0, 0, 0);
+      }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = wm * 64 + 32 * i + r;
+        bf16x8 bv = *reinterpret_cast<const bf16x8*>(xt + row * 128 + (((2 * kk + hh) ^ ((row >> 1) & 7)) << 4));
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2frag[kk], bv, acc[i], 0, 0, 0);
+      }
+
+    T* yg = reinterpret_cast<T*>(p.y) + (long long)b * p.y_bs;
+    const int len_out = p.lens_out ? p.lens_out[b] : 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int t = t0 + wm * 64 + 32 * i + r;
+      const float keep_row = (t >= len_out) ? 0.f : 1.f;
+      unsigned yp[8];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (acc[i][4 * g + k] + bval[4 * g + k]) * keep_row;
+        yp[2 * g] = pack_bf16x2(o[0], o[1]);
+        yp[2 * g + 1] = pack_bf16x2(o[2], o[3]);
+      }
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          auto sw = __builtin_amdgcn_permlane32_swap(yp[4 * h2 + d], yp[4 * h2 + 2 + d], false, false);
+          yp[4 * h2 + d] = sw[0]; yp[4 * h2 + 2 + d] = sw[1];
+        }
+      if (t < p.Tout) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        T* dst = yg + (long long)t * p.ldy + n0 + wn * 32 + 8 * hh;
+        *reinterpret_cast<u32x4*>(dst) = u32x4{yp[0], yp[1], yp[2], yp[3]};
+        *reinterpret_cast<u32x4*>(dst + 16) = u32x4{yp[4], yp[5], yp[6], yp[7]};
+      }
+    }
+  }
+}
+
+static int launch_conv1x1_fold(ConvArgs p, const void* zero_page, hipStream_t stream) {
+  p.tiles_per_batch = (p.Tout + FO_ROWS - 1) / FO_ROWS;
+  const int ntiles = p.tiles_per_batch * p.B;
+  int nwg = std::min(256, std::max(8, (ntiles + 1) / 2));     // one workgroup per CU (96 KiB of LDS)
+  nwg = (nwg + 7) / 8 * 8;
+  const int tpw = (ntiles + nwg - 1) / nwg;
+  dim3 grid((unsigned)nwg, (unsigned)(p.Cout / 128));
+  (void)hipFuncSetAttribute((const void*)conv1x1_fold_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  conv1x1_fold_kernel<<<grid, FO_NT, 2 * FO_STAGE, stream>>>(p, (const __bf16*)zero_page, tpw);
+  SMT_CHECK_LAUNCH("conv1x1_fold");
+  return 0;
+}
+
 static int launch_conv1x1_dma(ConvArgs p, const void* zero_page, hipStream_t stream) {
   p.tiles_per_batch = (p.Tout + DMA_BM - 1) / DMA_BM;
   const int ntiles = p.tiles_per_batch * p.B;
@@ -1094,13 +1244,19 @@ static void conv_args_from_desc(const smt_conv_desc* d, ConvArgs& p) {
   p.site_width = d->site_width; p.drop_thresh16 = d->drop_thresh16; p.drop_scale = d->drop_scale;
   p.tiles_per_batch = 0;
   p.rs = 1;
+  p.x2 = d->x2; p.w2 = d->w2; p.bias2 = d->bias2; p.lens_in2 = d->lens_in2; p.x2_bs = d->bs_x2; p.ldx2 = d->ld_x2;
   { static int dbg = getenv("SMT_CONV_DBG") ? atoi(getenv("SMT_CONV_DBG")) : 0; p.dbg = dbg; }
 }
 
-enum ConvKernelKind { K_GENERIC, K_1X1, K_DMA, K_WS };
+enum ConvKernelKind { K_GENERIC, K_1X1, K_DMA, K_WS, K_FOLD };
+static bool conv_fold_eligible(const smt_conv_desc* d) {
+  return d->x2 && d->w2 && d->c_in2 == 64 && d->taps == 1 && d->c_in == 128 && !d->res && !d->act_grad && !d->act_out &&
+         d->y && d->ld_x2 % 8 == 0;
+}
 // the one dispatch rule (smt_conv1d_ntc and smt_conv1d_kernel_name both use it)
 static ConvKernelKind pick_kernel(const smt_conv_desc* d, const ConvArgs& p0) {
   if (!conv_dma_eligible(d)) return K_GENERIC;
+  if (d->x2) return conv_fold_eligible(d) ? K_FOLD : K_GENERIC;
   if (d->taps == 1 && d->c_in == 128) return K_1X1;
   ConvArgs p = p0;
   DmaPlan pl;
@@ -1133,7 +1289,11 @@ extern "C" int smt_conv1d_ntc(const smt_conv_desc* d, smt_stream_t stream_) {
   if (d->batch == 0 || d->t_out == 0) return 0;
   ConvArgs p;
   conv_args_from_desc(d, p);
-  switch (pick_kernel(d, p)) {
+  const ConvKernelKind kind = pick_kernel(d, p);
+  SMT_CHECK_ARG(!d->x2 || kind == K_FOLD,
+                "smt_conv1d_ntc: the folded second term needs the bf16 1x1 LDS-DMA path (c_in 128, c_in2 64, no other epilogue)");
+  switch (kind) {
+    case K_FOLD: return launch_conv1x1_fold(p, d->zero_page, stream);
     case K_1X1: return launch_conv1x1_dma(p, d->zero_page, stream);
     case K_DMA: case K_WS: return launch_conv_dma(p, d->zero_page, stream);
     default: break;
@@ -1149,6 +1309,7 @@ extern "C" const char* smt_conv1d_kernel_name(const smt_conv_desc* d) {
   conv_args_from_desc(d, p);
   switch (pick_kernel(d, p)) {
     case K_1X1: return "conv1x1_dma";
+    case K_FOLD: return "conv1x1_fold";
     case K_WS: return "conv_ws";
     case K_DMA: return "conv_gemm_dma";
     default: return "conv_gemm";

@@ -15,6 +15,7 @@
 // reduces the chunks in fixed order (deterministic) into the fp32 torch-layout gradient.  The bias
 // gradient rides along as one extra "tap" whose x operand is the constant 1.
 #include <algorithm>
+#include <cstdlib>
 
 #include "conv_common.h"
 
@@ -379,6 +380,182 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(WgradArgs p, const 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Shifted-fragment variant for the dilated 128-channel convs (bf16, stride 1, <= 9 taps at distance 1 in the
+// row domain -- natively, or after the dilation-class decomposition of conv_gemm_dma_kernel: rows t = cls (mod
+// dilation) form `rs` independent dense problems).  The x operand of tap s is the x operand of tap 0 moved down
+// s rows, and an MFMA B fragment holds 8 consecutive rows per lane, so all taps of a k-step are windows of ONE
+// 16-row register window W = [P | Q] (P: rows 16 k0 + 8 hh + 0..7, Q: the next 8):
+//     even s: B_s = dwords s/2 .. s/2+3 of W (register renaming, free)
+//     odd  s: B_s[i] = v_alignbit(W[(s+1)/2 + i], W[(s-1)/2 + i], 16)
+// Per k-step a wave reads 3 fragments from LDS (dy^T, P, Q) for up to 9 (+1 bias) MFMAs, where the per-tap
+// kernel above reads one per MFMA -- that kernel is LDS-bandwidth bound.  All taps are handled in one launch
+// (accumulators: 10 planes x 16 registers), and a workgroup walks a contiguous range of 128-row tiles across
+// (batch, class) items, so the number of partial slabs does not grow with the number of classes.
+struct ShiftArgs {
+  const void* x; const void* dy; float* slab; const int* lens_in;
+  long long x_bs, dy_bs;
+  int ldx, ldy;
+  int B, Tin, Tout, pad, rs;
+  int tiles_per_item, tiles_per_wg, n_chunks, nblk_ci, nblk_co, with_bias;
+};
+
+constexpr int SH_R = 128, SH_XROWS = SH_R + 8, SH_DY = SH_R * 128, SH_X = SH_XROWS * 256, SH_STAGE = SH_DY + SH_X;
+
+template <int NTAPS>
+__global__ __launch_bounds__(512) void conv_wgrad_shift_kernel(ShiftArgs p, const __bf16* __restrict__ zero_page) {
+  typedef __bf16 T;
+  constexpr int CB = 64, CIB = 128, WNC = 4, NTHR = 512, DYB = CB * 2, XB = CIB * 2, PLANES = NTAPS + 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WNC, wn = wave % WNC;
+  const int r = lane & 31, hh = lane >> 5;
+
+  const int nblk = p.nblk_ci * p.nblk_co;
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int blk = q % nblk;
+  const int cgl = (q / nblk) * 8 + xcd;
+  if (cgl >= p.n_chunks) return;
+  const int co0 = (blk / p.nblk_ci) * CB, ci0 = (blk % p.nblk_ci) * CIB;
+  const int ntiles = p.tiles_per_item * p.B * p.rs;
+  const int tile_begin = cgl * p.tiles_per_wg;
+  const int tile_end = min(ntiles, tile_begin + p.tiles_per_wg);
+  const int rs = p.rs;
+  const bool bias_plane = p.with_bias && (ci0 == 0);
+
+  f32x16 acc[PLANES];
+#pragma unroll
+  for (int j = 0; j < PLANES; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+  auto stage = [&](int tile, int buf) {
+    const int item = tile / p.tiles_per_item;
+    const int b = item / rs, cls = item - b * rs;
+    const int t0 = (tile - item * p.tiles_per_item) * SH_R;
+    const int Tc = (p.Tout - cls + rs - 1) / rs;
+    const T* xg = reinterpret_cast<const T*>(p.x) + (long long)b * p.x_bs + (long long)cls * p.ldx + ci0;
+    const T* dyg = reinterpret_cast<const T*>(p.dy) + (long long)b * p.dy_bs + (long long)cls * p.ldy + co0;
+    const long long ldx = (long long)p.ldx * rs, ldy = (long long)p.ldy * rs;
+    const int len_full = p.lens_in ? min(p.lens_in[b], p.Tin) : p.Tin;
+    const int len_in = max(0, (len_full - cls + rs - 1) / rs);
+    unsigned char* base = smem + (size_t)buf * SH_STAGE;
+    // dy: 128 rows x 8 chunks; one wave-instruction = 8 rows
+#pragma unroll
+    for (int g = wave; g < SH_R / 8; g += NTHR / 64) {
+      const int row = 8 * g + (lane >> 3), pos = lane & 7;
+      const int t = t0 + row;
+      const int ch = pos ^ (((row >> 1) & 1) << 2);
+      wg_dma16((t < Tc) ? dyg + (long long)t * ldy + ch * 8 : zero_page + pos * 8, base + g * 1024);
+    }
+    // x: 136 rows x 16 chunks; one wave-instruction = 4 rows
+    const int tin0 = t0 - p.pad;
+    for (int g = wave; g < SH_XROWS / 4; g += NTHR / 64) {
+      const int row = 4 * g + (lane >> 4), pos = lane & 15;
+      const int tin = tin0 + row;
+      const bool ok = (row < SH_R + NTAPS - 1) && (tin >= 0) && (tin < len_in);
+      const int ch = pos ^ ((row & 3) << 2);
+      wg_dma16(ok ? xg + (long long)tin * ldx + ch * 8 : zero_page + pos * 8, base + SH_DY + g * 1024);
+    }
+  };
+
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+  // per-lane fragment offsets: the k-step advances rows by 16, which keeps both swizzle terms
+  const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3, thh = tg >> 1;
+  const int coly = wm * 32 + 16 * (tg & 1) + 4 * tp, colx = wn * 32 + 16 * (tg & 1) + 4 * tp;
+  const int lrow = 8 * thh + tq;
+  const int dyoff = lrow * DYB + (((coly >> 3) ^ (((lrow >> 1) & 1) << 2)) << 4) + (coly & 7) * 2;
+  const int xoff = SH_DY + lrow * XB + (((colx >> 3) ^ ((lrow & 3) << 2)) << 4) + (colx & 7) * 2;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  auto tr2u = [&](const unsigned char* pa) -> u32x4 {      // rows +0..3 and +4..7 of this lane's column
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)pa);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa + 4 * XB));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(u32x4, v);
+  };
+
+  if (tile_begin < tile_end) stage(tile_begin, 0);
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    const int buf = (tile - tile_begin) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                       // this tile has landed for every wave; the other buffer is free
+    if (tile + 1 < tile_end) stage(tile + 1, buf ^ 1);
+    const unsigned char* base = smem + (size_t)buf * SH_STAGE;
+#pragma unroll
+    for (int k0 = 0; k0 < SH_R / 16; ++k0) {
+      bf16x8 a;
+      {
+        const unsigned char* pa = base + dyoff + k0 * 16 * DYB;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)pa);
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa + 4 * DYB));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        a = __builtin_bit_cast(bf16x8, v);
+      }
+      const u32x4 pw = tr2u(base + xoff + k0 * 16 * XB);
+      const u32x4 qw = tr2u(base + xoff + k0 * 16 * XB + 8 * XB);
+      const unsigned w[8] = {pw[0], pw[1], pw[2], pw[3], qw[0], qw[1], qw[2], qw[3]};
+#pragma unroll
+      for (int s = 0; s < NTAPS; ++s) {
+        const int m = s >> 1;
+        u32x4 bw;
+        if (s & 1) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) bw[i] = __builtin_amdgcn_alignbit(w[m + i + 1], w[m + i], 16);
+        } else {
+          bw = u32x4{w[m], w[m + 1], w[m + 2], w[m + 3]};
+        }
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, bw), acc[s], 0, 0, 0);
+      }
+      if (bias_plane) acc[NTAPS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ones, acc[NTAPS], 0, 0, 0);
+    }
+  }
+  float* out = p.slab + ((size_t)cgl * nblk + blk) * (size_t)PLANES * CB * CIB;
+#pragma unroll
+  for (int j = 0; j < PLANES; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+      out[((size_t)j * CB + row) * CIB + wn * 32 + r] = acc[j][e];
+    }
+}
+
+// plan of the shifted-fragment variant; false = not applicable
+struct ShiftPlan { int rs, pad, tiles_per_item, tiles_per_wg, n_chunks, nblk_co, nblk_ci; };
+static bool wgrad_shift_plan(const smt_conv_desc* d, ShiftPlan* pl) {
+  static const bool off = getenv("SMT_WGRAD_NO_SHIFT") != nullptr;
+  if (off || d->dtype != SMT_BF16 || d->stride != 1 || d->out_stride != 1 || d->out_offset != 0 || !d->zero_page ||
+      d->c_in % 128 != 0 || d->c_out % 64 != 0 || d->taps < 3 || d->taps > 9 || !(d->taps & 1) || d->t_in != d->t_out)
+    return false;
+  int rs = 1, pad = d->padding;
+  if (d->dilation > 1) {
+    if (d->padding % d->dilation != 0 || d->t_out / d->dilation < 512) return false;
+    rs = d->dilation; pad = d->padding / d->dilation;
+  }
+  if (pad < 0 || pad > d->taps - 1) return false;
+  const long long tc_max = (d->t_out + rs - 1) / rs;
+  const int tpi = (int)((tc_max + SH_R - 1) / SH_R);
+  const long long ntiles = (long long)tpi * d->batch * rs;
+  if (ntiles < 512) return false;                       // small levels: the per-tap kernel wastes less
+  const int nco = d->c_out / 64, nci = d->c_in / 128;
+  const long long chunks_target = std::max<long long>(8, 256 / (nco * nci));   // one workgroup per CU
+  const int tpw = (int)((ntiles + chunks_target - 1) / chunks_target);
+  pl->rs = rs; pl->pad = pad; pl->tiles_per_item = tpi; pl->tiles_per_wg = tpw;
+  pl->n_chunks = (int)((ntiles + tpw - 1) / tpw); pl->nblk_co = nco; pl->nblk_ci = nci;
+  return true;
+}
+
+template <int NTAPS>
+static void launch_shift(const ShiftArgs& a, const void* zero_page, dim3 grid, hipStream_t stream) {
+  (void)hipFuncSetAttribute((const void*)conv_wgrad_shift_kernel<NTAPS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+  conv_wgrad_shift_kernel<NTAPS><<<grid, 512, 2 * SH_STAGE, stream>>>(a, (const __bf16*)zero_page);
+}
+
 struct WreduceArgs {
   const float* slab; float* dw; float* db;
   int n_chunks, nblk, nblk_ci, planes, taps, Cin, Cout, with_bias, cib;
@@ -491,6 +668,9 @@ static smt_conv_desc wgrad_group_desc(const smt_conv_desc* d, int j0, int n) {
 
 extern "C" size_t smt_conv1d_wgrad_workspace_bytes(const smt_conv_desc* d) {
   size_t best = 0;
+  ShiftPlan pl;
+  if (wgrad_shift_plan(d, &pl))
+    best = (size_t)pl.n_chunks * pl.nblk_co * pl.nblk_ci * (d->taps + 1) * 64 * 128 * sizeof(float);
   for (int j0 = 0; j0 < d->taps; j0 += WG_GROUP) {
     smt_conv_desc g = wgrad_group_desc(d, j0, std::min(WG_GROUP, d->taps - j0));
     best = std::max(best, wgrad_group_ws(&g));
@@ -589,6 +769,28 @@ extern "C" int smt_conv1d_wgrad(const smt_conv_desc* d, float* dweight, int64_t 
   hipStream_t stream = (hipStream_t)stream_;
   SMT_CHECK_ARG(d && tap_map, "smt_conv1d_wgrad: null pointer");
   SMT_CHECK_ARG(d->taps >= 1 && d->taps <= 16, "smt_conv1d_wgrad: taps must be in [1, 16]");
+  ShiftPlan pl;
+  if (wgrad_shift_plan(d, &pl)) {      // all taps in one launch, fragments shifted in registers
+    SMT_CHECK_ARG(d->x && d->y && dweight && workspace, "smt_conv1d_wgrad: null pointer");
+    SMT_CHECK_ARG(d->ld_x % 8 == 0 && d->ld_y % 8 == 0, "smt_conv1d_wgrad: pitches must keep 16-byte alignment");
+    SMT_CHECK_ARG(workspace_bytes >= smt_conv1d_wgrad_workspace_bytes(d), "smt_conv1d_wgrad: workspace too small");
+    ShiftArgs a;
+    a.x = d->x; a.dy = d->y; a.slab = (float*)workspace; a.lens_in = d->lens_in;
+    a.x_bs = d->bs_x; a.dy_bs = d->bs_y; a.ldx = d->ld_x; a.ldy = d->ld_y;
+    a.B = d->batch; a.Tin = d->t_in; a.Tout = d->t_out; a.pad = pl.pad; a.rs = pl.rs;
+    a.tiles_per_item = pl.tiles_per_item; a.tiles_per_wg = pl.tiles_per_wg; a.n_chunks = pl.n_chunks;
+    a.nblk_ci = pl.nblk_ci; a.nblk_co = pl.nblk_co; a.with_bias = dbias ? 1 : 0;
+    dim3 grid((unsigned)(8 * ((pl.n_chunks + 7) / 8) * pl.nblk_co * pl.nblk_ci));
+    switch (d->taps) {
+      case 3: launch_shift<3>(a, d->zero_page, grid, stream); break;
+      case 5: launch_shift<5>(a, d->zero_page, grid, stream); break;
+      case 7: launch_shift<7>(a, d->zero_page, grid, stream); break;
+      default: launch_shift<9>(a, d->zero_page, grid, stream); break;
+    }
+    SMT_CHECK_LAUNCH("conv_wgrad_shift");
+    return launch_wgrad_reduce((const float*)workspace, dweight, dbias, pl.n_chunks, pl.nblk_co, pl.nblk_ci, d->taps,
+                               d->c_in, d->c_out, 128, stride_out, stride_in, stride_tap, tap_map, stream);
+  }
   for (int j0 = 0; j0 < d->taps; j0 += WG_GROUP) {
     smt_conv_desc g = wgrad_group_desc(d, j0, std::min(WG_GROUP, d->taps - j0));
     int rc = wgrad_group(&g, dweight, stride_out, stride_in, stride_tap, tap_map + j0, j0 == 0 ? dbias : nullptr,

@@ -38,7 +38,10 @@ class ConvDesc(ctypes.Structure):
                 ("bs_act", ctypes.c_int64), ("bs_yact", ctypes.c_int64), ("x", ctypes.c_void_p), ("w", ctypes.c_void_p),
                 ("bias", ctypes.c_void_p), ("y", ctypes.c_void_p), ("y_act", ctypes.c_void_p), ("res", ctypes.c_void_p),
                 ("act_grad_src", ctypes.c_void_p), ("lens_in", ctypes.c_void_p), ("lens_out", ctypes.c_void_p),
-                ("w_swizzled", ctypes.c_int), ("zero_page", ctypes.c_void_p)]
+                ("w_swizzled", ctypes.c_int), ("zero_page", ctypes.c_void_p),
+                ("x2", ctypes.c_void_p), ("w2", ctypes.c_void_p), ("bias2", ctypes.c_void_p),
+                ("lens_in2", ctypes.c_void_p), ("c_in2", ctypes.c_int), ("ld_x2", ctypes.c_int),
+                ("bs_x2", ctypes.c_int64)]
 
 
 @dataclass
@@ -482,18 +485,20 @@ class _GatedHiFi(torch.autograd.Function):
         br = [params[6 * d:6 * d + 6] for d in range(depth)]
         wg, bg = params[6 * depth], params[6 * depth + 1]
 
-        # K1 for all branches at once
+        # K1 for all branches at once.  On the LDS-DMA path (bf16, 2w == 128, w == 64) only the activated
+        # output u1 is written: K3 recomputes its residual h1 = K1(x) + b1 from x (folded second term).
+        fold = _dma_ok(dt, c2, c2) and c2 == 128 and w == 64
         w1cat = torch.cat([p[0] for p in br], dim=0)
         b1cat = torch.cat([p[1] for p in br], dim=0)
-        h1 = torch.empty(b, t, depth * c2, dtype=dt, device=dev)
-        u1 = torch.empty_like(h1)
-        d1 = _base_desc(x, h1, lens32, w, depth * c2, 1, 1, 1, 0, t)
+        u1 = torch.empty(b, t, depth * c2, dtype=dt, device=dev)
+        h1 = None if fold else torch.empty_like(u1)
+        d1 = _base_desc(x, h1, lens32, w, depth * c2, 1, 1, 1, 0, t, t_y=t)
         d1.w, d1.bias = _p(_pack_fwd(w1cat, dt)), _p(b1cat)
         _set_act_out(d1, u1, [specs[d][0][0] for d in range(depth)], thresh, scale, c2)
         _launch(d1, "conv_fwd", _conv_flops(d1), _conv_bytes(d1, x.element_size()))
 
-        u2 = torch.empty_like(h1)
-        z = torch.empty_like(h1)
+        u2 = torch.empty_like(u1)
+        z = torch.empty_like(u1)
         for d, (k, dil, pad) in enumerate(geometry):
             sl = slice(d * c2, (d + 1) * c2)
             u1_d, u2_d = u1[:, :, sl], u2[:, :, sl]
@@ -513,8 +518,14 @@ class _GatedHiFi(torch.autograd.Function):
             d3.w, d3.bias = _p(wp3), _p(br[d][5])
             if dma:
                 _use_dma(d3, wp3)
-            d3.res, d3.bs_res, d3.ld_res = _geom(h1[:, :, sl])
-            _launch(d3, "conv_fwd", _conv_flops(d3), _conv_bytes(d3, x.element_size()))
+            if fold:
+                w1p = _pack_fwd(br[d][0], dt)                   # [2w][w], plain layout
+                d3.x2, d3.bs_x2, d3.ld_x2 = _geom(x)
+                d3.w2, d3.bias2, d3.c_in2, d3.lens_in2 = _p(w1p), _p(br[d][1]), w, _p(lens32)
+            else:
+                d3.res, d3.bs_res, d3.ld_res = _geom(h1[:, :, sl])
+            _launch(d3, "conv_fwd", _conv_flops(d3) * (1.0 + (0.5 if fold else 0.0)),
+                    _conv_bytes(d3, x.element_size()))
         del h1
         g = torch.empty(b, t, w, dtype=dt, device=dev)
         with profiler.region("gate_mix_fwd", nbytes=z.numel() * z.element_size() * 1.125, bound="hbm"):

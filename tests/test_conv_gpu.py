@@ -357,3 +357,65 @@ def test_fused_1x1_backward_matches_separate_kernels(b, t):
     assert float((dw[:, :, 0].double() - dw64).abs().max()) <= 20 * tol
     assert float((dw - dw_ref).abs().max()) <= 20 * tol
     assert float((db.double() - db64).abs().max()) <= 1e-5 * float(db64.abs().max()) + 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,t", [(3, 700), (2, 20011)])
+def test_folded_1x1_conv_matches_float64(b, t):
+    """conv1x1_fold (y = W u + b + W2 x2 + b2, the K3 + recomputed-K1 residual of GatedHiFiBlock) against a float64
+    evaluation of the same bf16 operands; x2 rows beyond lens read as 0, u rows are not masked."""
+    from smt_amd import convops as C
+    g = torch.Generator(device="cuda").manual_seed(11 * b + t)
+    c, w_in = 128, 64
+    u_big = torch.randn(b, t, 512, device="cuda", generator=g).to(torch.bfloat16)
+    u = u_big[:, :, 256:384]
+    x = torch.randn(b, t, w_in, device="cuda", generator=g).to(torch.bfloat16)
+    w3 = torch.randn(c, c, 1, device="cuda", generator=g) / c ** 0.5
+    w1 = torch.randn(c, w_in, 1, device="cuda", generator=g) / w_in ** 0.5
+    b3, b1 = torch.randn(c, device="cuda", generator=g), torch.randn(c, device="cuda", generator=g)
+    lens = torch.tensor([t, t // 3, 1][:b], device="cuda", dtype=torch.int32)
+    z_big = torch.zeros(b, t, 512, device="cuda", dtype=torch.bfloat16)
+    z = z_big[:, :, 128:256]
+    wp3, wp1 = C._pack_fwd(w3, torch.bfloat16, True), C._pack_fwd(w1, torch.bfloat16)
+    d = C._base_desc(u, z, None, c, c, 1, 1, 1, 0, t)
+    d.bias = C._p(b3)
+    C._use_dma(d, wp3)
+    d.x2, d.bs_x2, d.ld_x2 = C._geom(x)
+    d.w2, d.bias2, d.c_in2, d.lens_in2 = C._p(wp1), C._p(b1), w_in, C._p(lens)
+    assert C._kernel_of(d) == "conv1x1_fold"
+    C._launch(d, "t")
+    torch.cuda.synchronize()
+    mask = (torch.arange(t, device="cuda")[None, :] < lens[:, None]).double()[:, :, None]
+    ref = (torch.einsum("bti,oi->bto", u.double(), w3[:, :, 0].to(torch.bfloat16).double()) + b3.double()
+           + torch.einsum("bti,oi->bto", x.double() * mask, w1[:, :, 0].to(torch.bfloat16).double()) + b1.double())
+    err = (z.double() - ref).abs()
+    assert float(err.max()) <= 2.0 ** -8 * float(ref.abs().max()) + 1e-3       # one bf16 rounding of the result
+    assert float(z_big[:, :, :128].abs().max()) == 0 and float(z_big[:, :, 256:].abs().max()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,dil", [(3, 1), (5, 3), (7, 9), (9, 27)])
+def test_shifted_fragment_wgrad_matches_float64(k, dil):
+    """conv_wgrad_shift_kernel (all taps of a dilated conv from one 16-row register window per k-step, dilation
+    classes, tile ranges across (batch, class) items) against a float64 evaluation of the same bf16 operands, on
+    enough rows for it to be dispatched; ragged lens, operands that are channel slices of wider tensors."""
+    from smt_amd import convops as C
+    g = torch.Generator(device="cuda").manual_seed(200 + k)
+    b, t, c = 3, 50021, 128
+    xb = torch.randn(b, t, 256, device="cuda", generator=g).to(torch.bfloat16)
+    dyb = torch.randn(b, t, 384, device="cuda", generator=g).to(torch.bfloat16)
+    x, dy = xb[:, :, 128:256], dyb[:, :, 128:256]
+    lens = torch.tensor([t, 33333, 1], device="cuda", dtype=torch.int32)
+    pad = (k - 1) * dil // 2
+    dw, db = torch.empty(c, c, k, device="cuda"), torch.empty(c, device="cuda")
+    d = C._base_desc(x, dy, lens, c, c, k, 1, dil, pad, t)
+    C._wgrad(d, dw, c * k, k, 1, list(range(k)), db)
+    torch.cuda.synchronize()
+    mask = (torch.arange(t, device="cuda")[None, :] < lens[:, None])[:, :, None]
+    xm = torch.where(mask, x, torch.zeros_like(x)).double()
+    xp = torch.nn.functional.pad(xm, (0, 0, pad, pad))
+    ref = torch.stack([torch.einsum("bto,bti->oi", dy.double(), xp[:, s * dil:s * dil + t]) for s in range(k)], dim=2)
+    tol = 2e-6 * float(ref.abs().max()) * (b * t) ** 0.5 + 1e-4     # fp32 accumulation over b*t rows
+    assert float((dw.double() - ref).abs().max()) <= tol
+    dbr = dy.double().sum((0, 1))
+    assert float((db.double() - dbr).abs().max()) <= 2e-6 * float(dbr.abs().max()) * (b * t) ** 0.5 + 1e-3

@@ -137,7 +137,7 @@ typedef struct smt_conv_desc {
 } smt_conv_desc;
 int smt_conv1d_ntc(const smt_conv_desc* desc, smt_stream_t stream);
 /* Name of the kernel smt_conv1d_ntc dispatches this descriptor to ("conv_gemm", "conv_gemm_dma", "conv_ws",
- * "conv1x1_dma", "conv1x1_fold"): for profilers and tests; no device work. */
+ * "conv1x1_dma", "conv1x1_fold", "conv_k1act"): for profilers and tests; no device work. */
 const char* smt_conv1d_kernel_name(const smt_conv_desc* desc);
 
 /* Weight (+ bias) gradient of the same convolution:

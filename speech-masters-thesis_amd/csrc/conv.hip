@@ -1062,6 +1062,143 @@ static int launch_conv1x1_fold(ConvArgs p, const void* zero_page, hipStream_t st
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// K1 of GatedHiFiBlock for all branches at once when only the ACTIVATED output is wanted (bf16, C_in = 64,
+// C_out = 512, y == NULL):  u = relu(dropout(W x + b)) -- 128 B in, 1 KiB out per row, an HBM-write-bound
+// layer.  Persistent workgroups; the 512 x 64 weight block lives in registers (wave w owns output channels
+// 64 w .. 64 w + 63); x tiles come through an LDS-DMA double buffer; transposed MFMA tiles, dropout hash and
+// ReLU on the accumulators, v_permlane32_swap pairing, 16-byte stores straight from registers.
+constexpr int K1_ROWS = 128, K1_NT = 512, K1_X = K1_ROWS * 128, K1_COUT = 512;
+
+__global__ __launch_bounds__(K1_NT) void conv_k1act_kernel(ConvArgs p, const __bf16* __restrict__ zero_page,
+                                                           int tiles_per_wg) {
+  typedef __bf16 T;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // 2 x [128 rows][128 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+
+  const int ntiles = p.tiles_per_batch * p.B;
+  const int nwg = gridDim.x;
+  const int wg = (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3);
+  const int tile_begin = wg * tiles_per_wg;
+  const int tile_end = min(ntiles, tile_begin + tiles_per_wg);
+  if (tile_begin >= tile_end) return;
+
+  bf16x8 wfrag[2][4];
+  float bval[2][16];
+  unsigned keys[2];
+  int cs[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int co = wave * 64 + 32 * c + r;
+    const unsigned char* wrow = reinterpret_cast<const unsigned char*>(p.w) + (size_t)co * 128;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) wfrag[c][kk] = *reinterpret_cast<const bf16x8*>(wrow + ((2 * kk + hh) << 4));
+    // accumulator element 4g + k of a lane = output channel col0 + 8g + k
+    const int col0 = wave * 64 + 32 * c + 4 * hh;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bval[c][e] = p.bias ? p.bias[col0 + 8 * (e >> 2) + (e & 3)] : 0.f;
+    const int site = col0 / p.site_width;            // a 32-channel tile never straddles a site (site_width % 32 == 0)
+    keys[c] = p.drop_keys[site & 7];
+    cs[c] = col0 - site * p.site_width;
+  }
+
+  auto stage = [&](int tile, int buf) {
+    const int b = tile / p.tiles_per_batch;
+    const int t0 = (tile - b * p.tiles_per_batch) * K1_ROWS;
+    const T* xg = reinterpret_cast<const T*>(p.x) + (long long)b * p.x_bs;
+    const int len_in = p.lens_in ? min(p.lens_in[b], p.Tin) : p.Tin;
+#pragma unroll
+    for (int q = 0; q < (K1_ROWS / 8) / (K1_NT / 64); ++q) {     // 8 rows x 8 chunks per instruction
+      const int g = wave + (K1_NT / 64) * q;
+      const int row = 8 * g + (lane >> 3), pos = lane & 7;
+      const int t = t0 + row;
+      // 128-byte rows: two rows share a 256-byte bank window, chunk c of row n sits at c ^ ((n >> 1) & 7)
+      lds_dma16(t < len_in ? xg + (long long)t * p.ldx + ((pos ^ ((row >> 1) & 7)) * 8) : zero_page + pos * 8,
+                smem + (size_t)buf * K1_X + g * 1024);
+    }
+  };
+
+  T* ug0 = reinterpret_cast<T*>(p.y_act);
+  stage(tile_begin, 0);
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    const int buf = (tile - tile_begin) & 1;
+    const int b = tile / p.tiles_per_batch;
+    const int t0 = (tile - b * p.tiles_per_batch) * K1_ROWS;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile has landed
+    __syncthreads();                                    // ... for every wave; the other buffer is free again
+    if (tile + 1 < tile_end) stage(tile + 1, buf ^ 1);
+    const unsigned char* xt = smem + (size_t)buf * K1_X;
+    T* ug = ug0 + (long long)b * p.ya_bs;
+    const int len_out = p.lens_out ? p.lens_out[b] : 0x7fffffff;
+#pragma unroll 1
+    for (int i = 0; i < K1_ROWS / 32; ++i) {
+      const int row = 32 * i + r;
+      f32x16 acc[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[c][e] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bf16x8 bv = *reinterpret_cast<const bf16x8*>(xt + row * 128 + (((2 * kk + hh) ^ ((row >> 1) & 7)) << 4));
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[c][kk], bv, acc[c], 0, 0, 0);
+      }
+      const int t = t0 + row;
+      const float keep_row = (t >= len_out) ? 0.f : 1.f;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        unsigned up[8];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const unsigned long long base = ((unsigned long long)b * p.Ty + t) * p.site_width + (cs[c] + 8 * g);
+          float o[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] = (float)(T)(acc[c][4 * g + k] + bval[c][4 * g + k]) * keep_row;
+#pragma unroll
+          for (int k = 0; k < 4; k += 2) {
+            const unsigned h = fmix32((unsigned)((base + k) >> 1) * 0x9E3779B1u + keys[c]);
+            const bool k0 = (h & 0xFFFFu) >= p.drop_thresh16, k1 = (h >> 16) >= p.drop_thresh16;
+            up[2 * g + (k >> 1)] = pack_bf16x2((k0 && o[k] > 0.f) ? o[k] * p.drop_scale : 0.f,
+                                               (k1 && o[k + 1] > 0.f) ? o[k + 1] * p.drop_scale : 0.f);
+          }
+        }
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            auto sw = __builtin_amdgcn_permlane32_swap(up[4 * h2 + d], up[4 * h2 + 2 + d], false, false);
+            up[4 * h2 + d] = sw[0]; up[4 * h2 + 2 + d] = sw[1];
+          }
+        if (t < p.Tout) {
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          T* dst = ug + (long long)t * p.ldya + wave * 64 + 32 * c + 8 * hh;
+          *reinterpret_cast<u32x4*>(dst) = u32x4{up[0], up[1], up[2], up[3]};
+          *reinterpret_cast<u32x4*>(dst + 16) = u32x4{up[4], up[5], up[6], up[7]};
+        }
+      }
+    }
+  }
+}
+
+static bool conv_k1act_eligible(const smt_conv_desc* d) {
+  return d->dtype == SMT_BF16 && d->taps == 1 && d->c_in == 64 && d->c_out == K1_COUT && d->stride == 1 &&
+         d->out_stride == 1 && d->out_offset == 0 && d->t_y == d->t_out && d->t_in == d->t_out && !d->y && d->act_out &&
+         d->y_act && !d->res && !d->act_grad && !d->x2 && d->zero_page && !d->w_swizzled && d->site_width % 32 == 0;
+}
+
+static int launch_conv_k1act(ConvArgs p, const void* zero_page, hipStream_t stream) {
+  p.tiles_per_batch = (p.Tout + K1_ROWS - 1) / K1_ROWS;
+  const int ntiles = p.tiles_per_batch * p.B;
+  int nwg = std::min(512, std::max(8, (ntiles + 1) / 2));     // two workgroups per CU (32 KiB of LDS each)
+  nwg = (nwg + 7) / 8 * 8;
+  const int tpw = (ntiles + nwg - 1) / nwg;
+  conv_k1act_kernel<<<nwg, K1_NT, 2 * K1_X, stream>>>(p, (const __bf16*)zero_page, tpw);
+  SMT_CHECK_LAUNCH("conv_k1act");
+  return 0;
+}
+
 static int launch_conv1x1_dma(ConvArgs p, const void* zero_page, hipStream_t stream) {
   p.tiles_per_batch = (p.Tout + DMA_BM - 1) / DMA_BM;
   const int ntiles = p.tiles_per_batch * p.B;
@@ -1248,13 +1385,14 @@ static void conv_args_from_desc(const smt_conv_desc* d, ConvArgs& p) {
   { static int dbg = getenv("SMT_CONV_DBG") ? atoi(getenv("SMT_CONV_DBG")) : 0; p.dbg = dbg; }
 }
 
-enum ConvKernelKind { K_GENERIC, K_1X1, K_DMA, K_WS, K_FOLD };
+enum ConvKernelKind { K_GENERIC, K_1X1, K_DMA, K_WS, K_FOLD, K_K1ACT };
 static bool conv_fold_eligible(const smt_conv_desc* d) {
   return d->x2 && d->w2 && d->c_in2 == 64 && d->taps == 1 && d->c_in == 128 && !d->res && !d->act_grad && !d->act_out &&
          d->y && d->ld_x2 % 8 == 0;
 }
 // the one dispatch rule (smt_conv1d_ntc and smt_conv1d_kernel_name both use it)
 static ConvKernelKind pick_kernel(const smt_conv_desc* d, const ConvArgs& p0) {
+  if (conv_k1act_eligible(d)) return K_K1ACT;
   if (!conv_dma_eligible(d)) return K_GENERIC;
   if (d->x2) return conv_fold_eligible(d) ? K_FOLD : K_GENERIC;
   if (d->taps == 1 && d->c_in == 128) return K_1X1;
@@ -1294,6 +1432,7 @@ extern "C" int smt_conv1d_ntc(const smt_conv_desc* d, smt_stream_t stream_) {
                 "smt_conv1d_ntc: the folded second term needs the bf16 1x1 LDS-DMA path (c_in 128, c_in2 64, no other epilogue)");
   switch (kind) {
     case K_FOLD: return launch_conv1x1_fold(p, d->zero_page, stream);
+    case K_K1ACT: return launch_conv_k1act(p, d->zero_page, stream);
     case K_1X1: return launch_conv1x1_dma(p, d->zero_page, stream);
     case K_DMA: case K_WS: return launch_conv_dma(p, d->zero_page, stream);
     default: break;
@@ -1310,6 +1449,7 @@ extern "C" const char* smt_conv1d_kernel_name(const smt_conv_desc* d) {
   switch (pick_kernel(d, p)) {
     case K_1X1: return "conv1x1_dma";
     case K_FOLD: return "conv1x1_fold";
+    case K_K1ACT: return "conv_k1act";
     case K_WS: return "conv_ws";
     case K_DMA: return "conv_gemm_dma";
     default: return "conv_gemm";

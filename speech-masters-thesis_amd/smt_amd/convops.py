@@ -495,6 +495,8 @@ class _GatedHiFi(torch.autograd.Function):
         d1 = _base_desc(x, h1, lens32, w, depth * c2, 1, 1, 1, 0, t, t_y=t)
         d1.w, d1.bias = _p(_pack_fwd(w1cat, dt)), _p(b1cat)
         _set_act_out(d1, u1, [specs[d][0][0] for d in range(depth)], thresh, scale, c2)
+        if fold:
+            d1.zero_page = _p(_zero_page(dev))     # enables the persistent activated-output kernel (conv_k1act)
         _launch(d1, "conv_fwd", _conv_flops(d1), _conv_bytes(d1, x.element_size()))
 
         u2 = torch.empty_like(u1)

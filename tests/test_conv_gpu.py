@@ -419,3 +419,36 @@ def test_shifted_fragment_wgrad_matches_float64(k, dil):
     assert float((dw.double() - ref).abs().max()) <= tol
     dbr = dy.double().sum((0, 1))
     assert float((db.double() - dbr).abs().max()) <= 2e-6 * float(dbr.abs().max()) * (b * t) ** 0.5 + 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,t,train", [(3, 700, True), (2, 20011, True), (2, 1000, False)])
+def test_k1_activated_output_kernel_matches_generic_kernel(b, t, train):
+    """conv_k1act (64 -> 512, only u = relu(dropout(W x + b)) written, four dropout sites) against the generic
+    kernel on the same inputs: bit-identical, ragged lens included."""
+    from smt_amd import convops as C
+    g = torch.Generator(device="cuda").manual_seed(13 * b + t)
+    w_in, c_out = 64, 512
+    x = torch.randn(b, t, w_in, device="cuda", generator=g).to(torch.bfloat16)
+    w = torch.randn(c_out, w_in, 1, device="cuda", generator=g) / w_in ** 0.5
+    bias = torch.randn(c_out, device="cuda", generator=g)
+    lens = torch.tensor([t, t // 3, 1][:b], device="cuda", dtype=torch.int32)
+    wp = C._pack_fwd(w, torch.bfloat16)
+    keys = [C.dropout_key(5, s) for s in range(4)] if train else [0] * 4
+    thresh, scale = (6554, 1.0 / 0.9) if train else (0, 1.0)
+    outs, names = [], []
+    for fast in (False, True):
+        u = torch.zeros(b, t, c_out, device="cuda", dtype=torch.bfloat16)
+        d = C._base_desc(x, None, lens, w_in, c_out, 1, 1, 1, 0, t, t_y=t)
+        d.w, d.bias = C._p(wp), C._p(bias)
+        d.lens_out = C._p(lens)
+        C._set_act_out(d, u, keys, thresh, scale, 128)
+        if fast:
+            d.zero_page = C._p(C._zero_page(x.device))
+        names.append(C._kernel_of(d))
+        C._launch(d, "t")
+        torch.cuda.synchronize()
+        outs.append(u)
+    assert names == ["conv_gemm", "conv_k1act"]
+    assert torch.equal(outs[0], outs[1])
+    assert outs[0].float().abs().sum() > 0

@@ -159,6 +159,18 @@ size_t smt_conv1x1_bwd_workspace_bytes(const smt_conv_desc* desc);
 int smt_conv1x1_bwd(const smt_conv_desc* desc, float* dweight, int64_t stride_out, int64_t stride_in, float* dbias,
                     void* workspace, size_t workspace_bytes, smt_stream_t stream);
 
+/* Fused backward of K1 of GatedHiFiBlock for all branches at once (bf16, 64 -> 512 1x1; resnet.py:205-216 and the
+ * block residual resnet.py:241):  dx[t,ci] = keep(t) * sum_co dh[t,co] * W[co][ci] + res[t,ci]  (keep = t < lens[b]),
+ * dweight[co*stride_out + ci*stride_in] = sum_t dh[t,co] * x[t,ci] (x rows >= lens[b] read as 0), dbias[co] = sum_t dh.
+ * dh [B,t,512], x / res / dx [B,t,64] with explicit pitches; w_packed_bwd = smt_pack_weight(..) layout [ci][co],
+ * swizzle 0; zero_page >= 256 zero bytes.  One pass over dh instead of a data-gradient and a weight-gradient pass. */
+size_t smt_conv_k1_bwd_workspace_bytes(int batch, int t);
+int smt_conv_k1_bwd(const void* dh, int64_t bs_dh, int ld_dh, const void* x, int64_t bs_x, int ld_x,
+                    const void* w_packed_bwd, const void* res, int64_t bs_res, int ld_res, void* dx, int64_t bs_dx,
+                    int ld_dx, const int* lens, int batch, int t, const void* zero_page, float* dweight,
+                    int64_t stride_out, int64_t stride_in, float* dbias, void* workspace, size_t workspace_bytes,
+                    smt_stream_t stream);
+
 /* sum_d tanh(t_d) * softmax_d(s_d) over `depth` branches laid side by side along the channel axis
  * (z[.., d*2w + c] = t_d, z[.., d*2w + w + c] = s_d) -- GatedHiFiBlock.forward, resnet.py:229-237. */
 int smt_gate_mix_fwd(const void* z, void* g, int dtype, int64_t rows, int width, int depth, int ld_z, int ld_g,

@@ -201,6 +201,21 @@ def _conv1x1_bwd(desc, dweight, s_out, s_in, dbias):
                                     N.stream_ptr()), "smt_conv1x1_bwd")
 
 
+def _conv_k1_bwd(dh, x, w_packed_bwd, res, dx, lens32, dweight, dbias):
+    """Fused data + weight gradient of the 64 -> 512 K1 layer (smt_conv_k1_bwd): one pass over dh."""
+    lib = N.lib()
+    b, t = x.shape[0], x.shape[1]
+    ws = N.workspace.get(lib.smt_conv_k1_bwd_workspace_bytes(b, t), x.device)
+    (pdh, bsdh, lddh), (px, bsx, ldx_), (pr, bsr, ldr), (pdx, bsdx, lddx) = _geom(dh), _geom(x), _geom(res), _geom(dx)
+    rows = float(b) * t
+    with profiler.region("conv_k1_bwd", flops=4.0 * rows * 512 * 64, nbytes=rows * (512 + 3 * 64) * 2, bound="hbm",
+                         dtype="bf16"):
+        N.check(lib.smt_conv_k1_bwd(pdh, bsdh, lddh, px, bsx, ldx_, _p(w_packed_bwd), pr, bsr, ldr, pdx, bsdx, lddx,
+                                    _p(lens32), b, t, _p(_zero_page(x.device)), _p(dweight), dweight.stride(0),
+                                    dweight.stride(1), _p(dbias), _p(ws), ws.numel(), N.stream_ptr()),
+                "smt_conv_k1_bwd")
+
+
 def _set_act_out(d, u, keys, thresh, scale, site_width):
     d.act_out, d.site_width = 1, site_width
     d.y_act, d.bs_yact, d.ld_yact = _geom(u)
@@ -609,12 +624,16 @@ class _GatedHiFi(torch.autograd.Function):
         # K1cat: dx = (dh1 . W1cat^T) * mask + dout ; dW1cat
         w1cat = torch.cat([p[0] for p in br], dim=0)
         dx = torch.empty_like(x)
-        d = _dgrad_stride1(dh1, _pack_bwd(w1cat, dt), dx, 1, 1, 0)
-        d.lens_out = _p(lens32)
-        d.res, d.bs_res, d.ld_res = _geom(dout)
-        _launch(d, "conv_dgrad", _conv_flops(d), _conv_bytes(d, x.element_size()))
         dw1cat, db1cat = torch.empty_like(w1cat), f32((depth * c2,))
-        _wgrad(_base_desc(x, dh1, lens32, w, depth * c2, 1, 1, 1, 0, t), dw1cat, w, 1, 1, [0], db1cat)
+        if dt == torch.bfloat16 and w == 64 and depth * c2 == 512:
+            # data gradient and weight gradient both stream the 1 KiB rows of dh1: one fused pass
+            _conv_k1_bwd(dh1, x, _pack_bwd(w1cat, dt), dout, dx, lens32, dw1cat, db1cat)
+        else:
+            d = _dgrad_stride1(dh1, _pack_bwd(w1cat, dt), dx, 1, 1, 0)
+            d.lens_out = _p(lens32)
+            d.res, d.bs_res, d.ld_res = _geom(dout)
+            _launch(d, "conv_dgrad", _conv_flops(d), _conv_bytes(d, x.element_size()))
+            _wgrad(_base_desc(x, dh1, lens32, w, depth * c2, 1, 1, 1, 0, t), dw1cat, w, 1, 1, [0], db1cat)
         for dd in range(depth):
             grads[6 * dd] = dw1cat[dd * c2:(dd + 1) * c2]
             grads[6 * dd + 1] = db1cat[dd * c2:(dd + 1) * c2]

@@ -452,3 +452,35 @@ def test_k1_activated_output_kernel_matches_generic_kernel(b, t, train):
     assert names == ["conv_gemm", "conv_k1act"]
     assert torch.equal(outs[0], outs[1])
     assert outs[0].float().abs().sum() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,t", [(3, 700), (2, 20011), (1, 1)])
+def test_fused_k1_backward_matches_separate_kernels(b, t):
+    """smt_conv_k1_bwd (one pass over dh) against the data-gradient conv + weight-gradient kernel it replaces: dx is
+    bit-identical, the fp32 weight / bias gradients match a float64 reference; ragged lens included."""
+    from smt_amd import convops as C
+    g = torch.Generator(device="cuda").manual_seed(17 * b + t)
+    w_in, c_out = 64, 512
+    dh = torch.randn(b, t, c_out, device="cuda", generator=g).to(torch.bfloat16)
+    x = torch.randn(b, t, w_in, device="cuda", generator=g).to(torch.bfloat16)
+    dout = torch.randn(b, t, w_in, device="cuda", generator=g).to(torch.bfloat16)
+    w = torch.randn(c_out, w_in, 1, device="cuda", generator=g) / w_in ** 0.5
+    lens = torch.tensor([t, t // 3, 1][:b], device="cuda", dtype=torch.int32)
+    wb = C._pack_bwd(w, torch.bfloat16)
+
+    dx_ref = torch.zeros(b, t, w_in, device="cuda", dtype=torch.bfloat16)
+    d = C._dgrad_stride1(dh, wb, dx_ref, 1, 1, 0)
+    d.lens_out = C._p(lens)
+    d.res, d.bs_res, d.ld_res = C._geom(dout)
+    C._launch(d, "t")
+    dx = torch.zeros_like(dx_ref)
+    dw, db = torch.empty_like(w), torch.empty(c_out, device="cuda")
+    C._conv_k1_bwd(dh, x, wb, dout, dx, lens, dw, db)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx_ref)
+    mask = (torch.arange(t, device="cuda")[None, :] < lens[:, None]).double()[:, :, None]
+    dw64 = torch.einsum("bto,bti->oi", dh.double(), x.double() * mask)
+    db64 = dh.double().sum((0, 1))
+    assert float((dw[:, :, 0].double() - dw64).abs().max()) <= 2e-6 * float(dw64.abs().max()) * (b * t) ** 0.5 + 1e-4
+    assert float((db.double() - db64).abs().max()) <= 2e-6 * float(db64.abs().max()) * (b * t) ** 0.5 + 1e-3

@@ -186,23 +186,35 @@ def main():
                     "traffic": traffic}
 
         dt = "bf16" if m.get("compute_dtype") == "bf16" else "f32"
-        # dominant single kernel by time: the LDS-DMA implicit-GEMM conv kernel (dilated convs, fwd + dgrad)
-        roofline = group({"conv_gemm_dma"}, "smt::conv_gemm_dma_kernel (dilated 128->128 convs, forward + data gradient)",
-                         "mfma", dt, "conv_gemm_dma_kernel")
+        # dominant kernel by time: the weight-stationary implicit-GEMM conv kernel (dilated 128->128 convs, fwd + dgrad)
+        roofline = group({"conv_ws"}, "smt::conv_ws_kernel (dilated 128->128 convs, forward + data gradient)",
+                         "mfma", dt, "conv_ws_kernel")
         if roofline is None:   # fp32 configuration: everything runs on the generic kernel
             roofline = group({"conv_gemm"}, "smt::conv_gemm_kernel", "mfma", dt, "conv_gemm_kernel")
         extra_rooflines = {
+            "conv_wgrad": group({"conv_wgrad"}, "smt::conv_wgrad_shift_kernel / conv_wgrad{,_dma}_kernel + reduce", "mfma",
+                                dt, "conv_wgrad_shift_kernel"),
+            "conv1x1_bwd": group({"conv1x1_bwd"}, "smt::conv1x1_bwd_kernel (fused K3 backward, HBM-bound)", "hbm", dt,
+                                 "conv1x1_bwd_kernel"),
+            "conv1x1_fold": group({"conv1x1_fold"}, "smt::conv1x1_fold_kernel (K3 + recomputed K1 residual, HBM-bound)",
+                                  "hbm", dt, "conv1x1_fold_kernel"),
+            "conv_k1act": group({"conv_k1act"}, "smt::conv_k1act_kernel (K1, activated output only, HBM-bound)", "hbm",
+                                dt, "conv_k1act_kernel"),
+            "conv_k1_bwd": group({"conv_k1_bwd"}, "smt::conv_k1_bwd_kernel (fused K1 backward, HBM-bound)", "hbm", dt,
+                                 "conv_k1_bwd_kernel"),
+            "conv_gemm_dma": group({"conv_gemm_dma"}, "smt::conv_gemm_dma_kernel (LDS-DMA streaming kernel, small levels)",
+                                   "mfma", dt, "conv_gemm_dma_kernel"),
             "conv1x1_dma": group({"conv1x1_dma"}, "smt::conv1x1_dma_kernel (persistent 1x1, HBM-bound)", "hbm", dt,
                                  "conv1x1_dma_kernel"),
             "conv_gemm": group({"conv_gemm"}, "smt::conv_gemm_kernel (register-staged generic path)", "mfma", dt,
                                "conv_gemm_kernel"),
-            "conv_wgrad": group({"conv_wgrad"}, "smt::conv_wgrad{,_dma}_kernel + reduce", "mfma", dt, "conv_wgrad"),
             "vq_forward": group({"vq_forward"}, "smt_vq_forward (mean, prep, score, finalize, rescore, reduce)", "hbm",
                                 "f32", "vq_forward"),
             "vq_ema_accumulate": group({"vq_ema_accumulate"}, "smt::vq_ema_accumulate_kernel", "hbm", "f32"),
             "gate_mix": group({"gate_mix_fwd", "gate_mix_bwd"}, "smt::gate_mix_{fwd,bwd}_kernel", "hbm", dt, "gate_mix"),
             "stft_loss": group({"stft_loss_fwd", "stft_loss_bwd"}, "smt::stft_loss_{fwd,bwd}_kernel", "hbm", "f32"),
         }
+        extra_rooflines = {k: v for k, v in extra_rooflines.items() if v is not None}
         line = {
             "metric": "LJSpeech utterances/sec per VQ-VAE train step",
             "value": args.batch * world * args.steps / elapsed,

@@ -143,7 +143,11 @@ def _conv_flops(d):
 
 
 def _conv_bytes(d, esz):
-    return float(d.batch) * (d.t_in * d.c_in + d.t_out * d.c_out) * esz + d.taps * d.c_in * d.c_out * esz
+    """Algorithmic HBM bytes of one launch: every operand row once (x, y and/or y_act, residual, activation source,
+    folded x2) plus the weights."""
+    outs = (1 if d.y else 0) + (1 if d.act_out else 0) + (1 if d.res else 0) + (1 if d.act_grad else 0)
+    rows_in = float(d.batch) * d.t_in * (d.c_in + (d.c_in2 if d.x2 else 0))
+    return (rows_in + float(d.batch) * d.t_out * d.c_out * outs) * esz + d.taps * d.c_in * d.c_out * esz
 
 
 def _phases(kernel, stride, padding):

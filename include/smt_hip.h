@@ -96,6 +96,21 @@ int smt_pack_weight(const float* src, void* dst, int dtype, int n_out, int n_in,
 /* swizzle = 1 (bf16, n_in % 128 == 0): LDS-DMA operand layout -- inside every group of 128 input channels the
  * 8-channel chunk c of row o is stored at chunk position c ^ (o & 15); pass w_swizzled = 1 with it. */
 
+/* The same repack for MANY weights in one launch.  `table_dev` is an array of smt_pack_entry in DEVICE memory (built
+ * once by the host: parameter storage is stable across optimiser steps); dst element index of (tap, o, i) is
+ * dst_offset + tap*dst_tap_stride + o*dst_row_stride + i' (i' = i, or the swizzled position for swizzle = 1), so several
+ * weights can be packed side by side into one operand (K1 of the four branches).  Block b of the launch handles elements
+ * [1024*block_local_dev[b], +1024) of table row block_entry_dev[b]. */
+typedef struct smt_pack_entry {
+  const float* src; void* dst;
+  int64_t stride_out, stride_in, stride_tap;
+  int64_t dst_offset, dst_tap_stride, dst_row_stride;
+  int dtype, n_out, n_in, taps, swizzle;
+  int tap_map[16];
+} smt_pack_entry;
+int smt_pack_weights_batched(const smt_pack_entry* table_dev, const int* block_entry_dev, const int* block_local_dev,
+                             int n_blocks, smt_stream_t stream);
+
 /* One implicit-GEMM convolution over channels-last activations (forward, or a data gradient, which
  * is the same computation on repacked weights):
  *   y[b, t*out_stride + out_offset, co] =

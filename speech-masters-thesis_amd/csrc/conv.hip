@@ -1342,9 +1342,44 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(PackArgs p) {
   }
 }
 
+// Table-driven repack of MANY weights in one launch (the table lives in device memory and is built once by the
+// host; parameter storage is stable across optimiser steps).  block_entry[b] = table row of block b,
+// block_local[b] = its index among that row's blocks; 1024 elements per block.
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const smt_pack_entry* __restrict__ table,
+                                                                   const int* __restrict__ block_entry,
+                                                                   const int* __restrict__ block_local) {
+  const smt_pack_entry e = table[block_entry[blockIdx.x]];
+  const long long total = (long long)e.taps * e.n_out * e.n_in;
+  const long long base = (long long)block_local[blockIdx.x] * 1024;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long long idx = base + u * 256 + threadIdx.x;
+    if (idx >= total) break;
+    const int i = (int)(idx % e.n_in);
+    const int o = (int)((idx / e.n_in) % e.n_out);
+    const int tap = (int)(idx / ((long long)e.n_in * e.n_out));
+    int ipos = i;
+    if (e.swizzle) ipos = (i & ~127) | ((((i >> 3) & 15) ^ (o & 15)) << 3) | (i & 7);
+    const float v = e.src[o * e.stride_out + i * e.stride_in + e.tap_map[tap] * e.stride_tap];
+    const long long d = e.dst_offset + (long long)tap * e.dst_tap_stride + (long long)o * e.dst_row_stride + ipos;
+    if (e.dtype == SMT_BF16) reinterpret_cast<__bf16*>(e.dst)[d] = (__bf16)v;
+    else reinterpret_cast<float*>(e.dst)[d] = v;
+  }
+}
+
 }  // namespace smt
 
 using namespace smt;
+
+extern "C" int smt_pack_weights_batched(const smt_pack_entry* table_dev, const int* block_entry_dev,
+                                        const int* block_local_dev, int n_blocks, smt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_blocks <= 0) return 0;
+  SMT_CHECK_ARG(table_dev && block_entry_dev && block_local_dev, "smt_pack_weights_batched: null pointer");
+  pack_weights_batched_kernel<<<(unsigned)n_blocks, 256, 0, stream>>>(table_dev, block_entry_dev, block_local_dev);
+  SMT_CHECK_LAUNCH("pack_weights_batched");
+  return 0;
+}
 
 extern "C" int smt_pack_weight(const float* src, void* dst, int dtype, int n_out, int n_in, int taps,
                                int64_t stride_out, int64_t stride_in, int64_t stride_tap, const int* tap_map,

@@ -90,13 +90,139 @@ def _i32(lens):
     return lens if lens.dtype == torch.int32 else lens.to(torch.int32)
 
 
+class PackEntry(ctypes.Structure):
+    """Mirror of ``smt_pack_entry`` (include/smt_hip.h)."""
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("stride_out", ctypes.c_int64),
+                ("stride_in", ctypes.c_int64), ("stride_tap", ctypes.c_int64), ("dst_offset", ctypes.c_int64),
+                ("dst_tap_stride", ctypes.c_int64), ("dst_row_stride", ctypes.c_int64), ("dtype", ctypes.c_int),
+                ("n_out", ctypes.c_int), ("n_in", ctypes.c_int), ("taps", ctypes.c_int), ("swizzle", ctypes.c_int),
+                ("tap_map", ctypes.c_int * 16)]
+
+
+class _PackCache:
+    """Packed operand copies of the weights, repacked in ONE table-driven launch when the weights have changed.
+
+    Every conv needs its fp32 torch-layout weight in operand layout (twice: forward and data-gradient layouts).
+    Packing per use costs ~390 tiny launches per train step.  Parameters keep their storage across optimiser steps
+    and bump ``_version`` when updated in place, so each (weights, layout) pair gets a persistent destination and a
+    row in a device-side table; the first use after an update repacks ALL rows with smt_pack_weights_batched.
+    Source tensors are held strongly so that an address can never be reused by a different tensor behind a key."""
+
+    MAX_ENTRIES = 8192
+
+    def __init__(self):
+        self.entries = {}        # key -> dict(dst, parts=[(weight, PackEntry)], versions)
+        self.order = []          # keys in table order
+        self.table = None        # (table_dev, block_entry_dev, block_local_dev, n_blocks, n_rows)
+        self.device = None
+
+    def get(self, key, build):
+        e = self.entries.get(key)
+        if e is None:
+            if len(self.entries) >= self.MAX_ENTRIES:
+                self.entries.clear(); self.order.clear(); self.table = None
+            e = build()
+            self.entries[key] = e
+            self.order.append(key)
+            self.table = None
+            self._launch([e])                       # first use: pack just this operand
+            e["versions"] = [w._version for w, _ in e["parts"]]
+            return e["dst"]
+        if e["versions"] != [w._version for w, _ in e["parts"]]:
+            self.repack_all()
+        return e["dst"]
+
+    def _upload(self, entries):
+        rows, blk_e, blk_l = [], [], []
+        for e in entries:
+            for _, pe in e["parts"]:
+                n = pe.taps * pe.n_out * pe.n_in
+                nb = (n + 1023) // 1024
+                blk_e += [len(rows)] * nb
+                blk_l += list(range(nb))
+                rows.append(pe)
+        arr = (PackEntry * len(rows))(*rows)
+        dev = entries[0]["dst"].device
+        table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        be = torch.tensor(blk_e, dtype=torch.int32).to(dev)
+        bl = torch.tensor(blk_l, dtype=torch.int32).to(dev)
+        return table, be, bl, len(blk_e)
+
+    def _launch(self, entries, cached=None):
+        table, be, bl, nb = cached if cached is not None else self._upload(entries)
+        N.check(N.lib().smt_pack_weights_batched(_p(table), _p(be), _p(bl), nb, N.stream_ptr()),
+                "smt_pack_weights_batched")
+        return table, be, bl, nb
+
+    def repack_all(self):
+        entries = [self.entries[k] for k in self.order]
+        by_dev = {}
+        for e in entries:
+            by_dev.setdefault(e["dst"].device, []).append(e)
+        if self.table is None:
+            self.table = {}
+        for dev, es in by_dev.items():
+            with profiler.region("pack_weights_batched", bound="hbm"):
+                self.table[dev] = self._launch(es, self.table.get(dev))
+            for e in es:
+                e["versions"] = [w._version for w, _ in e["parts"]]
+
+
+_pack_cache = _PackCache()
+
+
+def _pack_parts(parts, dtype, dst_shape):
+    """parts: [(weight, n_out, n_in, s_out, s_in, s_tap, tap_map, swizzle, dst_offset, dst_tap_stride, dst_row_stride)]
+    packed side by side into one operand of shape dst_shape; cached (see _PackCache)."""
+    key = (dtype, tuple(dst_shape)) + tuple(
+        (w.data_ptr(), tuple(w.shape), n_out, n_in, s_out, s_in, s_tap, tuple(tap_map), bool(swizzle), off, ts, rs_)
+        for (w, n_out, n_in, s_out, s_in, s_tap, tap_map, swizzle, off, ts, rs_) in parts)
+
+    def build():
+        dst = torch.empty(dst_shape, dtype=dtype, device=parts[0][0].device)
+        ps = []
+        for (w, n_out, n_in, s_out, s_in, s_tap, tap_map, swizzle, off, tap_stride, row_stride) in parts:
+            assert w.dtype == torch.float32 and w.is_cuda
+            pe = PackEntry()
+            pe.src, pe.dst = w.data_ptr(), dst.data_ptr()
+            pe.stride_out, pe.stride_in, pe.stride_tap = s_out, s_in, s_tap
+            pe.dst_offset, pe.dst_tap_stride, pe.dst_row_stride = off, tap_stride, row_stride
+            pe.dtype, pe.n_out, pe.n_in, pe.taps, pe.swizzle = _DT[dtype], n_out, n_in, len(tap_map), int(swizzle)
+            assert not swizzle or (dtype == torch.bfloat16 and n_in % 128 == 0)
+            for i, t in enumerate(tap_map):
+                pe.tap_map[i] = t
+            ps.append((w, pe))
+        return {"dst": dst, "parts": ps, "versions": None}
+
+    return _pack_cache.get(key, build)
+
+
 def _pack(weight, dtype, n_out, n_in, s_out, s_in, s_tap, tap_map, swizzle=False):
     taps = len(tap_map)
-    dst = torch.empty(taps, n_out, n_in, dtype=dtype, device=weight.device)
-    arr = (ctypes.c_int * taps)(*tap_map)
-    N.check(N.lib().smt_pack_weight(_p(weight), _p(dst), _DT[dtype], n_out, n_in, taps, s_out, s_in, s_tap, arr,
-                                    int(swizzle), N.stream_ptr()), "smt_pack_weight")
-    return dst
+    return _pack_parts([(weight, n_out, n_in, s_out, s_in, s_tap, list(tap_map), swizzle, 0, n_out * n_in, n_in)],
+                       dtype, (taps, n_out, n_in))
+
+
+def _pack_cat_fwd(weights, dtype):
+    """1x1 weights [O_d, I, 1] of several layers stacked along the output axis: operand [1][sum O_d][I]."""
+    n_in = weights[0].shape[1]
+    total = sum(w.shape[0] for w in weights)
+    parts, row0 = [], 0
+    for w in weights:
+        parts.append((w, w.shape[0], n_in, n_in, 1, 1, [0], False, row0 * n_in, total * n_in, n_in))
+        row0 += w.shape[0]
+    return _pack_parts(parts, dtype, (1, total, n_in))
+
+
+def _pack_cat_bwd(weights, dtype):
+    """Data-gradient operand [1][I][sum O_d] of the same stack (rows = input channels, columns = output channels)."""
+    n_in = weights[0].shape[1]
+    total = sum(w.shape[0] for w in weights)
+    parts, col0 = [], 0
+    for w in weights:
+        parts.append((w, n_in, w.shape[0], 1, n_in, 1, [0], False, col0, n_in * total, total))
+        col0 += w.shape[0]
+    return _pack_parts(parts, dtype, (1, n_in, total))
 
 
 _zero_pages = {}
@@ -507,12 +633,11 @@ class _GatedHiFi(torch.autograd.Function):
         # K1 for all branches at once.  On the LDS-DMA path (bf16, 2w == 128, w == 64) only the activated
         # output u1 is written: K3 recomputes its residual h1 = K1(x) + b1 from x (folded second term).
         fold = _dma_ok(dt, c2, c2) and c2 == 128 and w == 64
-        w1cat = torch.cat([p[0] for p in br], dim=0)
         b1cat = torch.cat([p[1] for p in br], dim=0)
         u1 = torch.empty(b, t, depth * c2, dtype=dt, device=dev)
         h1 = None if fold else torch.empty_like(u1)
         d1 = _base_desc(x, h1, lens32, w, depth * c2, 1, 1, 1, 0, t, t_y=t)
-        d1.w, d1.bias = _p(_pack_fwd(w1cat, dt)), _p(b1cat)
+        d1.w, d1.bias = _p(_pack_cat_fwd([p[0] for p in br], dt)), _p(b1cat)
         _set_act_out(d1, u1, [specs[d][0][0] for d in range(depth)], thresh, scale, c2)
         if fold:
             d1.zero_page = _p(_zero_page(dev))     # enables the persistent activated-output kernel (conv_k1act)
@@ -626,14 +751,13 @@ class _GatedHiFi(torch.autograd.Function):
                    list(range(k)), grads[6 * dd + 3])
         del dz, dh2
         # K1cat: dx = (dh1 . W1cat^T) * mask + dout ; dW1cat
-        w1cat = torch.cat([p[0] for p in br], dim=0)
         dx = torch.empty_like(x)
-        dw1cat, db1cat = torch.empty_like(w1cat), f32((depth * c2,))
+        dw1cat, db1cat = torch.empty(depth * c2, w, 1, dtype=torch.float32, device=dev), f32((depth * c2,))
         if dt == torch.bfloat16 and w == 64 and depth * c2 == 512:
             # data gradient and weight gradient both stream the 1 KiB rows of dh1: one fused pass
-            _conv_k1_bwd(dh1, x, _pack_bwd(w1cat, dt), dout, dx, lens32, dw1cat, db1cat)
+            _conv_k1_bwd(dh1, x, _pack_cat_bwd([p[0] for p in br], dt), dout, dx, lens32, dw1cat, db1cat)
         else:
-            d = _dgrad_stride1(dh1, _pack_bwd(w1cat, dt), dx, 1, 1, 0)
+            d = _dgrad_stride1(dh1, _pack_cat_bwd([p[0] for p in br], dt), dx, 1, 1, 0)
             d.lens_out = _p(lens32)
             d.res, d.bs_res, d.ld_res = _geom(dout)
             _launch(d, "conv_dgrad", _conv_flops(d), _conv_bytes(d, x.element_size()))

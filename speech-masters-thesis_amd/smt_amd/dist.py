@@ -16,7 +16,7 @@ def broadcast_module(module, src=0):
     """Make parameters and buffers identical on every rank (DDP's constructor does this)."""
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, src)
+            dist.broadcast(t, src)          # in place on the parameter itself: bumps its version (pack cache)
 
 
 class GradSync:

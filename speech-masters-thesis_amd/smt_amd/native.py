@@ -29,6 +29,7 @@ _SIGNATURES = {
     "smt_vq_ema_accumulate": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr]),
     "smt_vq_ema_apply": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_int, c_int, c_ptr, c_ptr]),
     "smt_pack_weight": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_ptr, c_int, c_ptr]),
+    "smt_pack_weights_batched": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_ptr]),
     "smt_conv1d_ntc": (c_int, [c_ptr, c_ptr]),
     "smt_conv1d_kernel_name": (ctypes.c_char_p, [c_ptr]),
     "smt_conv1d_wgrad_workspace_bytes": (c_size, [c_ptr]),

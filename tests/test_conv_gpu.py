@@ -484,3 +484,36 @@ def test_fused_k1_backward_matches_separate_kernels(b, t):
     db64 = dh.double().sum((0, 1))
     assert float((dw[:, :, 0].double() - dw64).abs().max()) <= 2e-6 * float(dw64.abs().max()) * (b * t) ** 0.5 + 1e-4
     assert float((db.double() - db64).abs().max()) <= 2e-6 * float(db64.abs().max()) * (b * t) ** 0.5 + 1e-3
+
+
+@pytest.mark.gpu
+def test_pack_cache_follows_in_place_weight_updates():
+    """Packed operand copies are cached per (weight storage, layout) and repacked in one table-driven launch when a
+    weight's version changes: outputs must follow an in-place (optimizer-style) update, forward and backward."""
+    from smt_amd import convops as C
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(2, 300, 32, device="cuda", generator=g, requires_grad=True)
+    ws = [torch.nn.Parameter(torch.randn(64, 32, 3, device="cuda", generator=g) * 0.1) for _ in range(3)]
+    bs = [torch.nn.Parameter(torch.randn(64, device="cuda", generator=g)) for _ in range(3)]
+
+    def run():
+        outs = []
+        for w, b in zip(ws, bs):
+            y = C._Conv1d.apply(x, w, b, None, None, 1, 1, 1)
+            (gx,) = torch.autograd.grad(y.square().sum(), x)
+            ref = torch.nn.functional.conv1d(x.detach().cpu().transpose(1, 2), w.detach().cpu(), b.detach().cpu(), padding=1)
+            assert float((y.detach().cpu() - ref.transpose(1, 2)).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-5
+            outs.append((y.detach().clone(), gx.clone()))
+        return outs
+
+    first = run()
+    n_entries = len(C._pack_cache.entries)
+    again = run()                                         # nothing changed: cache hits, no new entries
+    assert len(C._pack_cache.entries) == n_entries
+    assert all(torch.equal(a[0], b_[0]) and torch.equal(a[1], b_[1]) for a, b_ in zip(first, again))
+    with torch.no_grad():
+        for w in ws:
+            w.mul_(-0.5)                                  # in-place update bumps the version -> batched repack
+    changed = run()                                       # run() re-checks against torch with the NEW weights
+    assert len(C._pack_cache.entries) == n_entries
+    assert not torch.equal(first[0][0], changed[0][0]) and not torch.equal(first[0][1], changed[0][1])

@@ -136,54 +136,93 @@ __global__ __launch_bounds__(256) void conv_in_fwd_kernel(const float* __restric
   }
 }
 
-// partial[wg][co][taps+1]: thread (q = tid/C', co) accumulates over its rows, LDS-reduced over q
+// partial[wg][co][9] (taps 0..7, bias at 8).  A thread owns EPV consecutive channels of every (256 / lanes-per-row)-th
+// row of its workgroup's run of rows: 16-byte dy loads, the few x samples of a row are broadcast loads shared by
+// the lanes of that row; (b, t) advance incrementally (no division in the loop).  Row groups are summed by
+// wave shuffles, waves through LDS -- fixed order, bitwise reproducible.
 template <typename T>
 __global__ __launch_bounds__(256) void conv_in_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ dy,
                                                             const int* __restrict__ lens, float* __restrict__ partial,
                                                             int B, int Tin, int Tout, int C, int taps, int stride,
                                                             int pad, long long rows_per_wg) {
-  __shared__ float red[256 * 9];
-  const int co = threadIdx.x % C, q = threadIdx.x / C, nq = 256 / C;
+  constexpr int EPV = Tr<T>::EPV;
+  __shared__ float red[4][64][9];
+  const int lpr = C / EPV;                       // lanes per row (power of two, <= 64)
+  const int rpi = 256 / lpr;                     // rows per iteration
+  const int lr = threadIdx.x % lpr, rq = threadIdx.x / lpr;
   const long long r0 = (long long)blockIdx.x * rows_per_wg;
   const long long r1 = min((long long)B * Tout, r0 + rows_per_wg);
-  float acc[9];
+  float acc[EPV][9];
 #pragma unroll
-  for (int j = 0; j < 9; ++j) acc[j] = 0.f;
-  if (q < nq) {
-    for (long long bt = r0 + q; bt < r1; bt += nq) {
-      const int t = (int)(bt % Tout), b = (int)(bt / Tout);
-      const int len = lens ? min(lens[b], Tin) : Tin;
-      const float g = (float)dy[bt * C + co];
-      acc[8] += g;
-      for (int j = 0; j < taps; ++j) {
-        const int tin = t * stride + j - pad;
-        const float xv = (tin >= 0 && tin < len) ? x[(long long)b * Tin + tin] : 0.f;
-        acc[j] = fmaf(g, xv, acc[j]);
-      }
+  for (int e = 0; e < EPV; ++e)
+#pragma unroll
+    for (int j = 0; j < 9; ++j) acc[e][j] = 0.f;
+  long long bt = r0 + rq;
+  int b = (int)(bt / Tout), t = (int)(bt - (long long)b * Tout);
+  for (; bt < r1; bt += rpi) {
+    const int len = lens ? min(lens[b], Tin) : Tin;
+    const Vec<T, EPV> g = *reinterpret_cast<const Vec<T, EPV>*>(dy + bt * C + lr * EPV);
+    float xv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int tin = t * stride + j - pad;
+      xv[j] = (j < taps && tin >= 0 && tin < len) ? x[(long long)b * Tin + tin] : 0.f;
     }
-  }
 #pragma unroll
-  for (int j = 0; j < 9; ++j) red[threadIdx.x * 9 + j] = acc[j];
-  __syncthreads();
-  if (threadIdx.x < C) {
+    for (int e = 0; e < EPV; ++e) {
+      const float gv = (float)g.v[e];
+      acc[e][8] += gv;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[e][j] = fmaf(gv, xv[j], acc[e][j]);
+    }
+    t += rpi;
+    while (t >= Tout) { t -= Tout; ++b; }
+  }
+  // sum the row groups of a wave (lanes lr, lr + lpr, ...), then the four waves
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int e = 0; e < EPV; ++e)
+#pragma unroll
     for (int j = 0; j < 9; ++j) {
-      float s = 0.f;
-      for (int qq = 0; qq < nq; ++qq) s += red[(qq * C + threadIdx.x) * 9 + j];
-      partial[((size_t)blockIdx.x * C + threadIdx.x) * 9 + j] = s;
+      float v = acc[e][j];
+      for (int o = lpr; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+      acc[e][j] = v;
+    }
+  if (lane < lpr) {
+#pragma unroll
+    for (int e = 0; e < EPV; ++e)
+#pragma unroll
+      for (int j = 0; j < 9; ++j) red[wave][(lane * EPV + e) & 63][j] = acc[e][j];
+  }
+  __syncthreads();
+  // C <= 64 * (waves per row when lpr = 64) -- here C <= 64 * EPV / EPV: one thread per channel
+  if (threadIdx.x < C) {
+    const int nw = (lpr >= 64) ? 1 : 4;          // with 64 lanes per row a wave IS one row group per wave
+    for (int j = 0; j < 9; ++j) {
+      float s2 = 0.f;
+      for (int w2 = 0; w2 < nw; ++w2) s2 += red[w2][threadIdx.x & 63][j];
+      partial[((size_t)blockIdx.x * C + threadIdx.x) * 9 + j] = s2;
     }
   }
 }
 
+// One workgroup per output: thread i sums partials i, i + 256, ... in index order, then a fixed LDS tree.
 __global__ __launch_bounds__(256) void conv_in_wgrad_reduce_kernel(const float* __restrict__ partial, int n_wg, int C,
                                                                    int taps, float* __restrict__ dw,
                                                                    float* __restrict__ db) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= C * 9) return;
+  __shared__ float part[256];
+  const int e = blockIdx.x;
   const int co = e / 9, j = e % 9;
   if (j >= taps && j != 8) return;
   float s = 0.f;
-  for (int g = 0; g < n_wg; ++g) s += partial[((size_t)g * C + co) * 9 + j];
-  if (j == 8) db[co] = s; else dw[co * taps + j] = s;
+  for (int g = threadIdx.x; g < n_wg; g += 256) s += partial[((size_t)g * C + co) * 9 + j];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { if (j == 8) db[co] = part[0]; else dw[co * taps + j] = part[0]; }
 }
 
 // ------------------------------------------------------------------ conv_out ----
@@ -267,11 +306,18 @@ __global__ __launch_bounds__(256) void conv_out_bwd_kernel(const T* __restrict__
 
 __global__ __launch_bounds__(256) void conv_out_reduce_kernel(const float* __restrict__ partial, int n_wg, int C,
                                                               float* __restrict__ dw, float* __restrict__ db) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e > C) return;
+  // one workgroup per output: thread i sums partials i, i + 256, ... in index order, then a fixed LDS tree
+  __shared__ float part[256];
+  const int e = blockIdx.x;
   float s = 0.f;
-  for (int g = 0; g < n_wg; ++g) s += partial[(size_t)g * (C + 1) + e];
-  if (e == C) db[0] = s; else dw[e] = s;
+  for (int g = threadIdx.x; g < n_wg; g += 256) s += partial[(size_t)g * (C + 1) + e];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { if (e == C) db[0] = part[0]; else dw[e] = part[0]; }
 }
 
 static unsigned ew_grid(long long total) { return (unsigned)std::min<long long>(4096, (total + 255) / 256); }
@@ -349,7 +395,12 @@ extern "C" int smt_conv_in_wgrad(const float* x, const void* dy, const int* lens
                                  int padding, void* workspace, size_t workspace_bytes, smt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SMT_CHECK_ARG(x && dy && dweight && dbias && workspace, "smt_conv_in_wgrad: null pointer");
-  SMT_CHECK_ARG(c_out <= 256 && 256 % c_out == 0 && taps >= 1 && taps <= 8, "smt_conv_in_wgrad: bad geometry");
+  {
+    const int epv = dtype == SMT_BF16 ? 8 : 4;
+    const int lpr = c_out / epv;
+    SMT_CHECK_ARG(c_out % epv == 0 && c_out <= 64 && lpr >= 1 && (lpr & (lpr - 1)) == 0 && taps >= 1 && taps <= 8,
+                  "smt_conv_in_wgrad: c_out must be a power-of-two multiple of the vector width, <= 64; taps <= 8");
+  }
   const long long rows = (long long)batch * t_out;
   const int n_wg = conv_in_wgs(rows);
   SMT_CHECK_ARG(workspace_bytes >= smt_conv_in_wgrad_workspace_bytes(batch, t_out, c_out),
@@ -362,7 +413,7 @@ extern "C" int smt_conv_in_wgrad(const float* x, const void* dy, const int* lens
     conv_in_wgrad_kernel<float><<<n_wg, 256, 0, stream>>>(x, (const float*)dy, lens, (float*)workspace, batch, t_in,
                                                          t_out, c_out, taps, stride, padding, rpw);
   SMT_CHECK_LAUNCH("conv_in_wgrad");
-  conv_in_wgrad_reduce_kernel<<<(c_out * 9 + 255) / 256, 256, 0, stream>>>((const float*)workspace, n_wg, c_out, taps,
+  conv_in_wgrad_reduce_kernel<<<c_out * 9, 256, 0, stream>>>((const float*)workspace, n_wg, c_out, taps,
                                                                            dweight, dbias);
   SMT_CHECK_LAUNCH("conv_in_wgrad_reduce");
   return 0;
@@ -408,7 +459,7 @@ extern "C" int smt_conv_out_bwd(const void* x, const float* weight, const int* l
     conv_out_bwd_kernel<float><<<n_wg, 256, 0, stream>>>((const float*)x, weight, lens, dy, (float*)dx,
                                                         (float*)workspace, batch, t, c_in, rpw);
   SMT_CHECK_LAUNCH("conv_out_bwd");
-  conv_out_reduce_kernel<<<(c_in + 1 + 255) / 256, 256, 0, stream>>>((const float*)workspace, n_wg, c_in, dweight, dbias);
+  conv_out_reduce_kernel<<<c_in + 1, 256, 0, stream>>>((const float*)workspace, n_wg, c_in, dweight, dbias);
   SMT_CHECK_LAUNCH("conv_out_reduce");
   return 0;
 }

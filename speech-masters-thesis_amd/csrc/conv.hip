@@ -665,9 +665,16 @@ __global__ __launch_bounds__(DMA_NT) void conv1x1_dma_kernel(ConvArgs p, const _
 constexpr int WS_AGPR_TAPS = 7;   // taps whose weights are pinned to AccVGPRs (7 x 32 = 224 of 256)
 constexpr int WS_BM = 128, WS_NT = 256, WS_EPI = 128 * 256;   // rows per tile, threads, epilogue-operand tile bytes
 
-template <int NTAPS>
+// MODE fixes the epilogue at compile time (straight-line code instead of ~85 branches in the unrolled epilogue, which
+// a single wave per SIMD cannot hide): 1 = activated output only (K2 forward), 2 = y with activation-gradient mask and
+// residual (K2 data gradient), 0 = whatever the descriptor asks for.
+template <int NTAPS, int MODE>
 __global__ __launch_bounds__(WS_NT) void conv_ws_kernel(ConvArgs p, const __bf16* __restrict__ zero_page,
                                                         int tiles_per_wg, int buf_bytes) {
+  const bool has_y = MODE == 0 ? (p.y != nullptr) : (MODE == 2);
+  const bool has_act_out = MODE == 0 ? (p.act_out != 0) : (MODE == 1);
+  const bool has_res = MODE == 0 ? (p.res != nullptr) : (MODE == 2);
+  const bool has_epi_act = MODE == 0 ? (p.epi_act != 0) : (MODE == 2);
   typedef __bf16 T;
   constexpr int EPV = 8, BM = WS_BM, BN = 128, KC = 128, NT = WS_NT, MW = BM / 32, ROWB = KC * 2;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -756,8 +763,8 @@ __global__ __launch_bounds__(WS_NT) void conv_ws_kernel(ConvArgs p, const __bf16
     // every wave is done reading the other buffer
     __syncthreads();
     if (tile + 1 < tile_end) stage_a(tile + 1, buf ^ 1);
-    if (p.res) stage_epi(reinterpret_cast<const T*>(p.res), p.res_bs, p.ldr, b, cls, t0, Tc, lds_res);
-    if (p.epi_act) stage_epi(reinterpret_cast<const T*>(p.gate_h), p.gh_bs, p.ldgh, b, cls, t0, Tc, lds_act);
+    if (has_res) stage_epi(reinterpret_cast<const T*>(p.res), p.res_bs, p.ldr, b, cls, t0, Tc, lds_res);
+    if (has_epi_act) stage_epi(reinterpret_cast<const T*>(p.gate_h), p.gh_bs, p.ldgh, b, cls, t0, Tc, lds_act);
 
     f32x16 acc[MW];
 #pragma unroll
@@ -793,10 +800,16 @@ __global__ __launch_bounds__(WS_NT) void conv_ws_kernel(ConvArgs p, const __bf16
     for (int q = 0; q < NTAPS * (KC / 16); ++q) {
       if (q + 1 < NTAPS * (KC / 16)) {
         const unsigned ap = frag_addr(q + 1);
+        if (ABL & 8) {           // ablation: no fragment reads after the first step
+#pragma unroll
+          for (int i = 0; i < MW; ++i) afr[(q + 1) & 1][i] = afr[q & 1][i];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
 #pragma unroll
         for (int i = 0; i < MW; ++i)
           asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(afr[(q + 1) & 1][i]) : "v"(ap), "n"(i * 32 * ROWB));
         asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        }
       } else {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
@@ -826,8 +839,8 @@ __global__ __launch_bounds__(WS_NT) void conv_ws_kernel(ConvArgs p, const __bf16
     }
 
     // ---- epilogue straight from the accumulators; same arithmetic as the other kernels: bf16(acc + bias) first
-    T* yg = p.y ? reinterpret_cast<T*>(p.y) + (long long)b * p.y_bs : nullptr;
-    T* ug = p.act_out ? reinterpret_cast<T*>(p.y_act) + (long long)b * p.ya_bs : nullptr;
+    T* yg = has_y ? reinterpret_cast<T*>(p.y) + (long long)b * p.y_bs : nullptr;
+    T* ug = has_act_out ? reinterpret_cast<T*>(p.y_act) + (long long)b * p.ya_bs : nullptr;
     const int len_out = p.lens_out ? p.lens_out[b] : 0x7fffffff;
 #pragma unroll
     for (int i = 0; i < MW; ++i) {
@@ -844,12 +857,12 @@ __global__ __launch_bounds__(WS_NT) void conv_ws_kernel(ConvArgs p, const __bf16
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = (float)(T)(acc[i][4 * g + k] + bval[4 * g + k]);
         const int eoff = row * 64 + ((g ^ swz) << 4) + 8 * hh;
-        if (p.epi_act) {
+        if (has_epi_act) {
           const bf16x4 uv = *reinterpret_cast<const bf16x4*>(lds_act + eoff);
 #pragma unroll
           for (int k = 0; k < 4; ++k) o[k] = ((float)uv[k] != 0.f) ? o[k] * p.drop_scale : 0.f;
         }
-        if (p.res) {
+        if (has_res) {
           const bf16x4 rv = *reinterpret_cast<const bf16x4*>(lds_res + eoff);
 #pragma unroll
           for (int k = 0; k < 4; ++k) o[k] = fmaf(o[k], keep_row, (float)rv[k]);
@@ -859,7 +872,7 @@ __global__ __launch_bounds__(WS_NT) void conv_ws_kernel(ConvArgs p, const __bf16
         }
         yp[2 * g] = pack_bf16x2(o[0], o[1]);
         yp[2 * g + 1] = pack_bf16x2(o[2], o[3]);
-        if (p.act_out) {
+        if (has_act_out) {
           const int col = col0 + 8 * g;
           const int site = col / p.site_width;
           const unsigned key = p.drop_keys[site & 7];
@@ -886,7 +899,7 @@ __global__ __launch_bounds__(WS_NT) void conv_ws_kernel(ConvArgs p, const __bf16
       };
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
       const int scol = n0 + wave * 32 + 8 * hh;
-      if (yg) {
+      if (has_y) {
         pair_up(yp);
         if (ok) {
           T* dst = yg + (long long)ty * p.ldy + scol;
@@ -894,7 +907,7 @@ __global__ __launch_bounds__(WS_NT) void conv_ws_kernel(ConvArgs p, const __bf16
           *reinterpret_cast<u32x4*>(dst + 16) = u32x4{yp[4], yp[5], yp[6], yp[7]};
         }
       }
-      if (ug) {
+      if (has_act_out) {
         pair_up(up);
         if (ok) {
           T* dst = ug + (long long)ty * p.ldya + scol;
@@ -906,11 +919,20 @@ __global__ __launch_bounds__(WS_NT) void conv_ws_kernel(ConvArgs p, const __bf16
   }
 }
 
+template <int NTAPS, int MODE>
+static void launch_ws_mode(const ConvArgs& p, const void* zero_page, dim3 grid, size_t lds, int tpw, int buf_bytes,
+                           hipStream_t stream) {
+  (void)hipFuncSetAttribute((const void*)conv_ws_kernel<NTAPS, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  conv_ws_kernel<NTAPS, MODE><<<grid, WS_NT, lds, stream>>>(p, (const __bf16*)zero_page, tpw, buf_bytes);
+}
+
 template <int NTAPS>
 static void launch_ws(const ConvArgs& p, const void* zero_page, dim3 grid, size_t lds, int tpw, int buf_bytes,
                       hipStream_t stream) {
-  (void)hipFuncSetAttribute((const void*)conv_ws_kernel<NTAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  conv_ws_kernel<NTAPS><<<grid, WS_NT, lds, stream>>>(p, (const __bf16*)zero_page, tpw, buf_bytes);
+  const bool y = p.y != nullptr, ao = p.act_out != 0, res = p.res != nullptr, ea = p.epi_act != 0;
+  if (!y && ao && !res && !ea) launch_ws_mode<NTAPS, 1>(p, zero_page, grid, lds, tpw, buf_bytes, stream);
+  else if (y && !ao && res && ea) launch_ws_mode<NTAPS, 2>(p, zero_page, grid, lds, tpw, buf_bytes, stream);
+  else launch_ws_mode<NTAPS, 0>(p, zero_page, grid, lds, tpw, buf_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

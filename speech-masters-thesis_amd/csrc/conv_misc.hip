@@ -113,26 +113,39 @@ __global__ __launch_bounds__(256) void conv_in_fwd_kernel(const float* __restric
                                                           T* __restrict__ y, int B, int Tin, int Tout, int C, int taps,
                                                           int stride, int pad) {
   constexpr int EPV = Tr<T>::EPV;
-  const int vpr = C / EPV;
-  const long long total = (long long)B * Tout * vpr;
-  for (long long f = (long long)blockIdx.x * 256 + threadIdx.x; f < total; f += (long long)gridDim.x * 256) {
-    const int cv = (int)(f % vpr);
-    const long long bt = f / vpr;
-    const int t = (int)(bt % Tout), b = (int)(bt / Tout);
+  const int vpr = C / EPV;                       // power of two <= 256: a thread keeps its channel vector for all rows
+  const int cv = threadIdx.x % vpr;
+  float wr[EPV][8], br[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) {
+    br[e] = bias[cv * EPV + e];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wr[e][j] = (j < taps) ? w[(cv * EPV + e) * taps + j] : 0.f;
+  }
+  // rows advance by a constant step: (b, t) are updated incrementally, no division in the loop
+  const long long rows = (long long)B * Tout;
+  const long long step = (long long)gridDim.x * (256 / vpr);
+  const int step_b = (int)(step / Tout), step_t = (int)(step % Tout);
+  long long bt = (long long)blockIdx.x * (256 / vpr) + threadIdx.x / vpr;
+  int b = (int)(bt / Tout), t = (int)(bt - (long long)b * Tout);
+  for (; bt < rows; bt += step) {
     const int len = lens ? min(lens[b], Tin) : Tin;
     float o[EPV];
 #pragma unroll
-    for (int e = 0; e < EPV; ++e) o[e] = bias[cv * EPV + e];
-    for (int j = 0; j < taps; ++j) {
-      const int tin = t * stride + j - pad;
-      const float xv = (tin >= 0 && tin < len) ? x[(long long)b * Tin + tin] : 0.f;
+    for (int e = 0; e < EPV; ++e) o[e] = br[e];
 #pragma unroll
-      for (int e = 0; e < EPV; ++e) o[e] = fmaf(xv, w[(cv * EPV + e) * taps + j], o[e]);
+    for (int j = 0; j < 8; ++j) {
+      const int tin = t * stride + j - pad;
+      const float xv = (j < taps && tin >= 0 && tin < len) ? x[(long long)b * Tin + tin] : 0.f;
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) o[e] = fmaf(xv, wr[e][j], o[e]);
     }
     Vec<T, EPV> out;
 #pragma unroll
     for (int e = 0; e < EPV; ++e) out.v[e] = (T)o[e];
     *reinterpret_cast<Vec<T, EPV>*>(y + bt * C + cv * EPV) = out;
+    b += step_b; t += step_t;
+    if (t >= Tout) { t -= Tout; ++b; }
   }
 }
 
@@ -371,7 +384,7 @@ extern "C" int smt_conv_in_fwd(const float* x, const float* weight, const float*
   hipStream_t stream = (hipStream_t)stream_;
   const int epv = dtype == SMT_BF16 ? 8 : 4;
   SMT_CHECK_ARG(x && weight && bias && y, "smt_conv_in_fwd: null pointer");
-  SMT_CHECK_ARG(c_out % epv == 0 && taps >= 1 && taps <= 8, "smt_conv_in_fwd: bad geometry");
+  SMT_CHECK_ARG(c_out % epv == 0 && taps >= 1 && taps <= 8 && 256 % (c_out / epv) == 0, "smt_conv_in_fwd: bad geometry");
   if (batch == 0 || t_out == 0) return 0;
   unsigned grid = ew_grid((long long)batch * t_out * (c_out / epv));
   if (dtype == SMT_BF16)

@@ -4,9 +4,9 @@
 # 8 no activation fragment reads, 16 no weight fragment reads.  Results are NOT numerically valid.
 set -e
 cd "$(dirname "$0")/../speech-masters-thesis_amd/csrc"
-for m in ${MASKS:-0 4 32 36}; do
+for m in ${MASKS:-0 8 32 40}; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=on -DSMT_ABL=$m -c conv.hip -o build/conv.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../smt_amd/libsmt_hip.so build/*.o
-  echo "== SMT_ABL=$m (conv_ws: 4 no MFMA loop, 32 no epilogue)"
+  echo "== SMT_ABL=$m (conv_ws: 4 no MFMA loop, 8 no fragment reads, 32 no epilogue)"
   python ../../tools/bench_dma.py 2>&1 | grep "dma=1"
 done

@@ -26,8 +26,9 @@ for (k, dil) in [(1, 1), (3, 1), (5, 3), (7, 9), (9, 27)]:
             if dma: C._use_dma(d, wp)
             if r is not None: d.res, d.bs_res, d.ld_res = C._geom(r)
             if act: C._set_act_out(d, u, [123], 6554, 1.111, 128)
+            if r is not None and act is None: C._set_act_grad(d, res, 1.111)
             C._launch(d, "x")
         flops = 2.0 * B * T * 128 * 128 * k
-        t1 = timeit(lambda: run()); t2 = timeit(lambda: run(res)); t3 = timeit(lambda: run(None, True, None))
+        t1 = timeit(lambda: run()); t2 = timeit(lambda: run(res)); t3 = timeit(lambda: run(None, True, None)); t4 = timeit(lambda: run(res, None))
         gb = B * T * 128 * 2 / 1e9
-        print(f"k={k} dil={dil:2d} dma={int(dma)}  plain {t1:7.1f} us ({flops/t1/1e6:6.1f} TF, {2*gb/t1*1e3:5.2f} TB/s)  +res {t2:7.1f} us ({3*gb/t2*1e3:5.2f} TB/s)  act-only {t3:7.1f} us")
+        print(f"k={k} dil={dil:2d} dma={int(dma)}  plain {t1:7.1f} us ({flops/t1/1e6:6.1f} TF, {2*gb/t1*1e3:5.2f} TB/s)  +res {t2:7.1f} us ({3*gb/t2*1e3:5.2f} TB/s)  act-only {t3:7.1f} us  res+actgrad {t4:7.1f} us")

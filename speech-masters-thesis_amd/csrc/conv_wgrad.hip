@@ -511,7 +511,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_shift_kernel(ShiftArgs p, cons
         }
         acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, bw), acc[s], 0, 0, 0);
       }
-      if (bias_plane) acc[NTAPS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ones, acc[NTAPS], 0, 0, 0);
+      // bias gradient: the four waves of a row share the k-steps (each column block of the bias plane then holds a
+      // PARTIAL sum; the reduce kernel adds columns 0, 32, 64, 96)
+      if (bias_plane && (k0 & 3) == wn) acc[NTAPS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ones, acc[NTAPS], 0, 0, 0);
     }
   }
   float* out = p.slab + ((size_t)cgl * nblk + blk) * (size_t)PLANES * CB * CIB;
@@ -559,6 +561,7 @@ static void launch_shift(const ShiftArgs& a, const void* zero_page, dim3 grid, h
 struct WreduceArgs {
   const float* slab; float* dw; float* db;
   int n_chunks, nblk, nblk_ci, planes, taps, Cin, Cout, with_bias, cib;
+  int bias_cols;   // the bias plane holds partial sums in columns 0, 32, .. 32 (bias_cols - 1): add them
   long long so, si, sj; int jmap[16];
 };
 
@@ -581,7 +584,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(WreduceArgs p) {
     const int blk = (co / 64) * p.nblk_ci + (ci / p.cib);
     const size_t blk_elems = (size_t)p.planes * 64 * p.cib;
     const float* src = p.slab + (size_t)blk * blk_elems + ((size_t)plane * 64 + (co % 64)) * p.cib + (ci % p.cib);
-    for (int c = sl; c < p.n_chunks; c += 8) s += src[(size_t)c * p.nblk * blk_elems];
+    if (plane == p.taps && p.bias_cols > 1) {
+      for (int c = sl; c < p.n_chunks; c += 8) {
+        const float* q = src + (size_t)c * p.nblk * blk_elems;
+        float part_sum = q[0];
+        for (int k = 1; k < p.bias_cols; ++k) part_sum += q[32 * k];
+        s += part_sum;
+      }
+    } else {
+      for (int c = sl; c < p.n_chunks; c += 8) s += src[(size_t)c * p.nblk * blk_elems];
+    }
   }
   part[sl][o] = s;
   __syncthreads();
@@ -632,8 +644,9 @@ static void wgrad_plan(const smt_conv_desc* d, int* rows_per_chunk, int* chunks_
 
 int launch_wgrad_reduce(const float* slab, float* dw, float* db, int n_chunks, int nblk_co, int nblk_ci, int taps,
                         int c_in, int c_out, int cib, long long so, long long si, long long sj, const int* jmap,
-                        hipStream_t stream) {
+                        hipStream_t stream, int bias_cols) {
   WreduceArgs r;
+  r.bias_cols = bias_cols;
   r.slab = slab; r.dw = dw; r.db = db;
   r.n_chunks = n_chunks; r.nblk = nblk_co * nblk_ci; r.nblk_ci = nblk_ci; r.planes = taps + 1; r.taps = taps;
   r.Cin = c_in; r.Cout = c_out; r.with_bias = db ? 1 : 0; r.cib = cib;
@@ -789,7 +802,7 @@ extern "C" int smt_conv1d_wgrad(const smt_conv_desc* d, float* dweight, int64_t 
     }
     SMT_CHECK_LAUNCH("conv_wgrad_shift");
     return launch_wgrad_reduce((const float*)workspace, dweight, dbias, pl.n_chunks, pl.nblk_co, pl.nblk_ci, d->taps,
-                               d->c_in, d->c_out, 128, stride_out, stride_in, stride_tap, tap_map, stream);
+                               d->c_in, d->c_out, 128, stride_out, stride_in, stride_tap, tap_map, stream, 4);
   }
   for (int j0 = 0; j0 < d->taps; j0 += WG_GROUP) {
     smt_conv_desc g = wgrad_group_desc(d, j0, std::min(WG_GROUP, d->taps - j0));

@@ -6,9 +6,11 @@
 //
 // Both need the 1 KiB row of dh, which is 3/4 of all bytes this layer moves; computed separately it is read twice.
 // A persistent workgroup streams 64-row tiles of dh (64 KiB) and x (8 KiB) through an LDS-DMA double buffer once:
-//   * data gradient: waves 0-3 each own one 32 x 32 tile of dx, transposed MFMA (A = W^T fragments fetched
-//     through L1 -- the 64 KiB weight block is re-read per tile, which is noise next to the dh stream), residual
-//     added in registers, v_permlane32_swap pairing, 16-byte stores;
+//   * data gradient: four 32 x 32 tiles of dx, each computed by TWO waves that split the 512 output channels (the
+//     contraction) in halves and keep their W^T fragments in registers (fetching them through L1 per tile left the
+//     kernel latency-bound: 1170 vs 695 us at the top level, tools/ablate_k1bwd.sh); the upper half hands its
+//     partial tile to the lower one through LDS (fixed order: bitwise reproducible), which adds the residual in
+//     registers, pairs lanes with v_permlane32_swap and stores 16-byte pieces;
 //   * weight gradient: wave w owns output channels 64 w .. 64 w + 63 (4 accumulator tiles + 2 bias tiles kept in
 //     registers for the whole run), fragments of dh^T and x through ds_read_b64_tr_b16.
 // Swizzles: dh rows are 1 KiB -- chunk c of row r sits at c ^ (((r & 3) << 2) | ((r >> 2) & 3)) (16 rows -> 16
@@ -31,6 +33,7 @@ struct K1BwdArgs {
 
 constexpr int KB_ROWS = 64, KB_CO = 512, KB_CI = 64, KB_NT = 512;
 constexpr int KB_DH = KB_ROWS * KB_CO * 2, KB_X = KB_ROWS * KB_CI * 2, KB_STAGE = KB_DH + KB_X;   // 64 KiB + 8 KiB
+constexpr int KB_RED = 4 * 32 * 32 * 4;   // partial data-gradient tiles of waves 4..7 (behind the two stages)
 
 __device__ __forceinline__ int kb_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 __device__ __forceinline__ int kb_swz_x(int row) { return ((row >> 1) & 3) << 1; }
@@ -45,7 +48,7 @@ __device__ __forceinline__ bf16x8 kb_tr2(const unsigned char* pa, const unsigned
 
 __global__ __launch_bounds__(KB_NT) void conv_k1_bwd_kernel(K1BwdArgs p, const __bf16* __restrict__ zero_page) {
   typedef __bf16 T;
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // 2 x [dh tile | x tile]
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // 2 x [dh tile | x tile], then the reduction scratch
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
 
@@ -101,9 +104,16 @@ __global__ __launch_bounds__(KB_NT) void conv_k1_bwd_kernel(K1BwdArgs p, const _
   const int offb0 = KB_DH + ra * 128 + (((col_b >> 3) ^ kb_swz_x(ra)) << 4) + (col_b & 7) * 2;
   const int offb1 = KB_DH + rb * 128 + (((col_b >> 3) ^ kb_swz_x(rb)) << 4) + (col_b & 7) * 2;
 
-  // data-gradient tile of waves 0..3: rows 32 i.., input channels 32 c..
-  const int di = (wave >> 1) & 1, dc = wave & 1;
-  const unsigned char* wrow = reinterpret_cast<const unsigned char*>(p.w) + (size_t)(32 * dc + r) * (KB_CO * 2);
+  // data-gradient tile of waves w and w + 4: rows 32 di.., input channels 32 dc..; wave w + 4 takes the upper half of
+  // the contraction (output channels 256..511).  W^T fragments (packed [ci][co], plain) live in registers.
+  const int di = (wave >> 1) & 1, dc = wave & 1, kh = wave >> 2;
+  bf16x8 wfrag[KB_CO / 32];
+  {
+    const unsigned char* wrow = reinterpret_cast<const unsigned char*>(p.w) + (size_t)(32 * dc + r) * (KB_CO * 2);
+#pragma unroll
+    for (int kk = 0; kk < KB_CO / 32; ++kk) wfrag[kk] = *reinterpret_cast<const bf16x8*>(wrow + ((2 * (kk + 16 * kh) + hh) << 4));
+  }
+  float* red = reinterpret_cast<float*>(smem + 2 * KB_STAGE) + (wave & 3) * 1024;   // [16 e][64 lanes] of tile (di, dc)
 
   if (tile_begin < tile_end) stage(tile_begin, 0);
   for (int tile = tile_begin; tile < tile_end; ++tile) {
@@ -115,50 +125,58 @@ __global__ __launch_bounds__(KB_NT) void conv_k1_bwd_kernel(K1BwdArgs p, const _
     if (tile + 1 < tile_end) stage(tile + 1, buf ^ 1);
     const unsigned char* base = smem + (size_t)buf * KB_STAGE;
 
-    if (wave < 4) {
-      // ---- data gradient, transposed: D^T[ci][row] = sum_co Wt[ci][co] * dh[row][co]   (Wt packed [ci][co], plain)
+    {
+      // ---- data gradient, transposed: D^T[ci][row] = sum_co Wt[ci][co] * dh[row][co], contraction split over two waves
       const int row = 32 * di + r;
       const int t = t0 + row;
-      const int len = p.lens ? p.lens[b] : 0x7fffffff;
-      const float keep_row = (t >= len) ? 0.f : 1.f;
-      // residual pieces of this lane: channels 32 dc + 8 g + 4 hh + 0..3
-      bf16x4 rv[4];
-      {
-        const T* rg = reinterpret_cast<const T*>(p.res) + (long long)b * p.res_bs + (long long)min(t, p.T - 1) * p.ldres + 32 * dc + 4 * hh;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) rv[g] = *reinterpret_cast<const bf16x4*>(rg + 8 * g);
-      }
       f32x16 accd;
 #pragma unroll
       for (int e = 0; e < 16; ++e) accd[e] = 0.f;
       const int swz_r = kb_swz(row);
-#pragma unroll 8
-      for (int kk = 0; kk < KB_CO / 16; ++kk) {
-        const bf16x8 av = *reinterpret_cast<const bf16x8*>(wrow + ((2 * kk + hh) << 4));
-        const bf16x8 bv = *reinterpret_cast<const bf16x8*>(base + row * 1024 + (((2 * kk + hh) ^ swz_r) << 4));
-        accd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, accd, 0, 0, 0);
+#pragma unroll
+      for (int kk = 0; kk < KB_CO / 32; ++kk) {
+        const bf16x8 bv = *reinterpret_cast<const bf16x8*>(base + row * 1024 + (((2 * (kk + 16 * kh) + hh) ^ swz_r) << 4));
+        accd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[kk], bv, accd, 0, 0, 0);
       }
-      unsigned yp[8];
+      if (kh) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float o[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = fmaf((float)(T)accd[4 * g + k], keep_row, (float)rv[g][k]);
-        yp[2 * g] = pack_bf16x2(o[0], o[1]);
-        yp[2 * g + 1] = pack_bf16x2(o[2], o[3]);
+        for (int e = 0; e < 16; ++e) red[e * 64 + lane] = accd[e];
       }
+      __syncthreads();                                  // partial tiles of waves 4..7 are in LDS
+      if (!kh) {
+        const int len = p.lens ? p.lens[b] : 0x7fffffff;
+        const float keep_row = (t >= len) ? 0.f : 1.f;
+        // residual pieces of this lane: channels 32 dc + 8 g + 4 hh + 0..3
+        bf16x4 rv[4];
+        {
+          const T* rg = reinterpret_cast<const T*>(p.res) + (long long)b * p.res_bs + (long long)min(t, p.T - 1) * p.ldres + 32 * dc + 4 * hh;
 #pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          auto sw = __builtin_amdgcn_permlane32_swap(yp[4 * h2 + d], yp[4 * h2 + 2 + d], false, false);
-          yp[4 * h2 + d] = sw[0]; yp[4 * h2 + 2 + d] = sw[1];
+          for (int g = 0; g < 4; ++g) rv[g] = *reinterpret_cast<const bf16x4*>(rg + 8 * g);
         }
-      if (t < p.T) {
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        T* dst = reinterpret_cast<T*>(p.dx) + (long long)b * p.dx_bs + (long long)t * p.lddx + 32 * dc + 8 * hh;
-        *reinterpret_cast<u32x4*>(dst) = u32x4{yp[0], yp[1], yp[2], yp[3]};
-        *reinterpret_cast<u32x4*>(dst + 16) = u32x4{yp[4], yp[5], yp[6], yp[7]};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accd[e] += red[e * 64 + lane];      // lower half + upper half, always in this order
+        unsigned yp[8];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float o[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] = fmaf((float)(T)accd[4 * g + k], keep_row, (float)rv[g][k]);
+          yp[2 * g] = pack_bf16x2(o[0], o[1]);
+          yp[2 * g + 1] = pack_bf16x2(o[2], o[3]);
+        }
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            auto sw = __builtin_amdgcn_permlane32_swap(yp[4 * h2 + d], yp[4 * h2 + 2 + d], false, false);
+            yp[4 * h2 + d] = sw[0]; yp[4 * h2 + 2 + d] = sw[1];
+          }
+        if (t < p.T) {
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          T* dst = reinterpret_cast<T*>(p.dx) + (long long)b * p.dx_bs + (long long)t * p.lddx + 32 * dc + 8 * hh;
+          *reinterpret_cast<u32x4*>(dst) = u32x4{yp[0], yp[1], yp[2], yp[3]};
+          *reinterpret_cast<u32x4*>(dst + 16) = u32x4{yp[4], yp[5], yp[6], yp[7]};
+        }
       }
     }
 
@@ -227,7 +245,7 @@ extern "C" int smt_conv_k1_bwd(const void* dh, int64_t bs_dh, int ld_dh, const v
     a.tiles_per_wg = (int)((ntiles + nwg - 1) / nwg);
     a.with_bias = dbias ? 1 : 0;
     (void)hipFuncSetAttribute((const void*)conv_k1_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    conv_k1_bwd_kernel<<<nwg, KB_NT, 2 * KB_STAGE, stream>>>(a, (const __bf16*)zero_page);
+    conv_k1_bwd_kernel<<<nwg, KB_NT, 2 * KB_STAGE + KB_RED, stream>>>(a, (const __bf16*)zero_page);
     SMT_CHECK_LAUNCH("conv_k1_bwd");
   }
   const int jmap[1] = {0};

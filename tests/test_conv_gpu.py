@@ -457,8 +457,8 @@ def test_k1_activated_output_kernel_matches_generic_kernel(b, t, train):
 @pytest.mark.gpu
 @pytest.mark.parametrize("b,t", [(3, 700), (2, 20011), (1, 1)])
 def test_fused_k1_backward_matches_separate_kernels(b, t):
-    """smt_conv_k1_bwd (one pass over dh) against the data-gradient conv + weight-gradient kernel it replaces: dx is
-    bit-identical, the fp32 weight / bias gradients match a float64 reference; ragged lens included."""
+    """smt_conv_k1_bwd (one pass over dh) against the data-gradient conv it replaces (within one bf16 rounding step,
+    bitwise reproducible run to run) and a float64 reference for dx and the fp32 weight / bias gradients; ragged lens."""
     from smt_amd import convops as C
     g = torch.Generator(device="cuda").manual_seed(17 * b + t)
     w_in, c_out = 64, 512
@@ -478,7 +478,18 @@ def test_fused_k1_backward_matches_separate_kernels(b, t):
     dw, db = torch.empty_like(w), torch.empty(c_out, device="cuda")
     C._conv_k1_bwd(dh, x, wb, dout, dx, lens, dw, db)
     torch.cuda.synchronize()
-    assert torch.equal(dx, dx_ref)
+    # the fused kernel splits the 512-channel contraction over two waves (lower half + upper half, fixed order), so
+    # its fp32 sums differ from the one-chain kernel in the last bits: at most one bf16 rounding step apart
+    diff = (dx.float() - dx_ref.float()).abs()
+    scale_c = dx_ref.float().abs() + dout.float().abs()      # >= |bf16(conv)|, whose rounding step bounds the difference
+    assert float((diff - 2.0 ** -6 * scale_c).max()) <= 1e-6
+    assert float((diff > 0).float().mean()) < 0.02
+    keep = (torch.arange(t, device="cuda")[None, :] < lens[:, None]).double()[:, :, None]
+    dx64 = torch.einsum("bto,oi->bti", dh.double(), w[:, :, 0].to(torch.bfloat16).double()) * keep + dout.double()
+    assert float(((dx.double() - dx64).abs() - 2.0 ** -6 * (dx64.abs() + dout.double().abs())).max()) <= 1e-2
+    dx2 = torch.zeros_like(dx)
+    C._conv_k1_bwd(dh, x, wb, dout, dx2, lens, dw, db)
+    assert torch.equal(dx, dx2)                      # run-to-run reproducible
     mask = (torch.arange(t, device="cuda")[None, :] < lens[:, None]).double()[:, :, None]
     dw64 = torch.einsum("bto,bti->oi", dh.double(), x.double() * mask)
     db64 = dh.double().sum((0, 1))

@@ -470,12 +470,20 @@ __global__ __launch_bounds__(512) void conv_wgrad_shift_kernel(ShiftArgs p, cons
   const int dyoff = lrow * DYB + (((coly >> 3) ^ (((lrow >> 1) & 1) << 2)) << 4) + (coly & 7) * 2;
   const int xoff = SH_DY + lrow * XB + (((colx >> 3) ^ ((lrow & 3) << 2)) << 4) + (colx & 7) * 2;
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  auto tr2u = [&](const unsigned char* pa) -> u32x4 {      // rows +0..3 and +4..7 of this lane's column
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)pa);
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa + 4 * XB));
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
-    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(u32x4, v);
+  // The three fragments of k-step k0+1 are requested (asm, so that the request stays where it is written) before the
+  // MFMAs of k-step k0; `s_waitcnt lgkmcnt(6)` then retires exactly the older six reads (LDS returns in order).  The
+  // fragments are operands of the wait so that nothing that uses them can be scheduled above it.
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  struct Frags { u32x2 a0, a1, p0, p1, q0, q1; };
+  auto request = [&](Frags& f, unsigned base, int k0) {
+    const unsigned pa = base + dyoff + k0 * 16 * DYB, px = base + xoff + k0 * 16 * XB;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.a0) : "v"(pa));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.a1) : "v"(pa), "n"(4 * DYB));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.p0) : "v"(px));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.p1) : "v"(px), "n"(4 * XB));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.q0) : "v"(px), "n"(8 * XB));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.q1) : "v"(px), "n"(12 * XB));
   };
 
   if (tile_begin < tile_end) stage(tile_begin, 0);
@@ -484,21 +492,21 @@ __global__ __launch_bounds__(512) void conv_wgrad_shift_kernel(ShiftArgs p, cons
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                       // this tile has landed for every wave; the other buffer is free
     if (tile + 1 < tile_end) stage(tile + 1, buf ^ 1);
-    const unsigned char* base = smem + (size_t)buf * SH_STAGE;
+    const unsigned base = lds0 + (unsigned)buf * SH_STAGE;
+    Frags fr[2];
+    request(fr[0], base, 0);
 #pragma unroll
     for (int k0 = 0; k0 < SH_R / 16; ++k0) {
-      bf16x8 a;
-      {
-        const unsigned char* pa = base + dyoff + k0 * 16 * DYB;
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)pa);
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa + 4 * DYB));
-        typedef short s16x8 __attribute__((ext_vector_type(8)));
-        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        a = __builtin_bit_cast(bf16x8, v);
+      Frags& f = fr[k0 & 1];
+      if (k0 + 1 < SH_R / 16) {
+        request(fr[(k0 + 1) & 1], base, k0 + 1);
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(f.a0), "+v"(f.a1), "+v"(f.p0), "+v"(f.p1), "+v"(f.q0), "+v"(f.q1) :: "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.a0), "+v"(f.a1), "+v"(f.p0), "+v"(f.p1), "+v"(f.q0), "+v"(f.q1) :: "memory");
       }
-      const u32x4 pw = tr2u(base + xoff + k0 * 16 * XB);
-      const u32x4 qw = tr2u(base + xoff + k0 * 16 * XB + 8 * XB);
-      const unsigned w[8] = {pw[0], pw[1], pw[2], pw[3], qw[0], qw[1], qw[2], qw[3]};
+      const u32x4 aw = {f.a0[0], f.a0[1], f.a1[0], f.a1[1]};
+      const bf16x8 a = __builtin_bit_cast(bf16x8, aw);
+      const unsigned w[8] = {f.p0[0], f.p0[1], f.p1[0], f.p1[1], f.q0[0], f.q0[1], f.q1[0], f.q1[1]};
 #pragma unroll
       for (int s = 0; s < NTAPS; ++s) {
         const int m = s >> 1;

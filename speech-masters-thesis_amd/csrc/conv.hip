@@ -18,6 +18,7 @@
 // mask, residual) and the stores are fully coalesced 16-byte accesses.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "smt_common.h"
 #include "conv_common.h"
@@ -919,6 +920,236 @@ __global__ __launch_bounds__(WS_NT) void conv_ws_kernel(ConvArgs p, const __bf16
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight-stationary kernel with the epilogue of tile i-1 hidden in the MFMA gaps of tile i (K2 forward: only the
+// activated output u = relu(dropout(y)) is written).  One wave per SIMD issues strictly in order, so the epilogue of
+// conv_ws_kernel (~1000 VALU instructions per tile at 4 cycles each) runs while the matrix core idles; but an
+// MFMA holds the vector issue port for only 8 of its 32 cycles, which leaves room for ~5 other instructions per MFMA.
+// Here the finished accumulators are packed to bf16 (32 registers) and the rest of the epilogue -- dropout hash,
+// ReLU, scaling, lane pairing, stores -- is cut into micro-steps of 2..10 instructions, one behind each MFMA of the
+// next tile (sched_barrier keeps them where they are written).  Taps 0..7 of the weight block are pinned to
+// AccVGPRs.  Same arithmetic as conv_ws_kernel: bit-identical outputs.
+template <int NTAPS>
+__global__ __launch_bounds__(WS_NT) void conv_ws_pipe_kernel(ConvArgs p, const __bf16* __restrict__ zero_page,
+                                                             int tiles_per_wg, int buf_bytes) {
+  typedef __bf16 T;
+  constexpr int EPV = 8, BM = WS_BM, BN = 128, KC = 128, NT = WS_NT, MW = BM / 32, ROWB = KC * 2;
+  constexpr int NSTEP = NTAPS * (KC / 16), NGAP = NSTEP * MW;
+  constexpr int PH_UNIT = 10, PH_ROW = 4 * PH_UNIT + 2, PH_TILE = MW * PH_ROW;
+  constexpr int AGPR_TAPS = NTAPS < 8 ? NTAPS : 8;
+  static_assert(MW == 4, "four accumulators");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int lrow = lane >> 4, lch = lane & 15;
+  const int n0 = blockIdx.y * BN;
+  const int rs = p.rs;
+
+  const int ntiles = p.tiles_per_batch * p.B * rs;
+  const int nwg = gridDim.x;
+  const int wg = (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3);
+  const int tile_begin = wg * tiles_per_wg;
+  const int tile_end = min(ntiles, tile_begin + tiles_per_wg);
+  if (tile_begin >= tile_end) return;
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+  bf16x8 wfrag[NTAPS][KC / 16];
+  {
+    const int co = n0 + wave * 32 + r;
+#pragma unroll
+    for (int s = 0; s < NTAPS; ++s) {
+      const unsigned char* wrow = reinterpret_cast<const unsigned char*>(p.w) + ((size_t)s * p.Cout + co) * ROWB;
+#pragma unroll
+      for (int kk = 0; kk < KC / 16; ++kk)
+        wfrag[s][kk] = *reinterpret_cast<const bf16x8*>(wrow + (((2 * kk + hh) ^ (co & 15)) << 4));
+    }
+  }
+  // accumulator element 4g + k of a lane = output channel col0 + 8g + k (this lane's row: 32 i + r)
+  const int col0 = n0 + wave * 32 + 4 * hh;
+  float bval[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) bval[e] = p.bias ? p.bias[col0 + 8 * (e >> 2) + (e & 3)] : 0.f;
+  unsigned keyg[4], cshalf[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int col = col0 + 8 * g;
+    const int site = col / p.site_width;
+    keyg[g] = p.drop_keys[site & 7];
+    cshalf[g] = (unsigned)(col - site * p.site_width) >> 1;
+  }
+  const int rows_in = BM + (NTAPS - 1) * p.dil;
+  const int rows_pad = (rows_in + 3) & ~3;
+
+  auto decode = [&](int tile, int& b, int& cls, int& t0) {
+    const int bb = tile / p.tiles_per_batch;
+    b = bb / rs; cls = bb - b * rs;
+    t0 = (tile - bb * p.tiles_per_batch) * BM;
+  };
+  auto stage_a = [&](int tile, int buf) {
+    int b, cls, t0;
+    decode(tile, b, cls, t0);
+    const T* xg = reinterpret_cast<const T*>(p.x) + (long long)b * p.x_bs + (long long)cls * p.ldx;
+    const long long ldx = (long long)p.ldx * rs;
+    const int len_full = p.lens_in ? min(p.lens_in[b], p.Tin) : p.Tin;
+    const int len_in = max(0, (len_full - cls + rs - 1) / rs);
+    const int tin0 = t0 - p.pad;
+    for (int g = wave; g < rows_pad / 4; g += NT / 64) {
+      const int row = 4 * g + lrow;
+      const int tin = tin0 + row;
+      const bool ok = (row < rows_in) && (tin >= 0) && (tin < len_in);
+      const T* src = ok ? xg + (long long)tin * ldx + ((lch ^ (row & 15)) * EPV) : zero_page + lch * EPV;
+      dma16(src, smem + (size_t)buf * buf_bytes + g * 1024);
+    }
+  };
+
+  // ---- state of the tile whose epilogue is pending
+  unsigned pc[MW][8];                 // bf16 pairs of (acc + bias): pc[i][2g + h] = elements 4g + 2h, 4g + 2h + 1
+  int p_b = 0, p_cls = 0, p_t0 = 0, p_Tc = 0, p_len = 0;
+  // ---- scratch of the micro-steps (live across MFMAs)
+  float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f, u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f, keepf = 1.f;
+  unsigned h0 = 0, h1 = 0, rh = 0, up[8];
+  int ty = 0;
+  auto fbits = [](unsigned v) { return __builtin_bit_cast(float, v); };
+  auto epi = [&](auto M) {           // micro-step M of the pending epilogue (M is a compile-time constant)
+    constexpr int m = decltype(M)::value;
+    constexpr int i = m / PH_ROW, rem = m % PH_ROW;
+    if constexpr (rem < 4 * PH_UNIT) {
+      constexpr int g = rem / PH_UNIT, ph = rem % PH_UNIT;
+      if constexpr (ph == 0) {
+        if constexpr (g == 0) {
+          const int tc = p_t0 + 32 * i + r;
+          ty = (tc < p_Tc) ? p_cls + rs * tc : -1;
+          keepf = (ty >= p_len) ? 0.f : 1.f;
+          rh = (unsigned)((((unsigned long long)p_b * p.Ty + (unsigned)max(ty, 0)) * (unsigned)p.site_width) >> 1);
+        }
+      } else if constexpr (ph == 1) {
+        o0 = fbits(pc[i][2 * g] << 16) * keepf; o1 = fbits(pc[i][2 * g] & 0xffff0000u) * keepf;
+      } else if constexpr (ph == 2) {
+        o2 = fbits(pc[i][2 * g + 1] << 16) * keepf; o3 = fbits(pc[i][2 * g + 1] & 0xffff0000u) * keepf;
+      } else if constexpr (ph == 3) {
+        h0 = (rh + cshalf[g]) * 0x9E3779B1u + keyg[g]; h1 = h0 + 0x9E3779B1u;
+      } else if constexpr (ph == 4) {
+        h0 ^= h0 >> 16; h0 *= 0x85EBCA6Bu; h1 ^= h1 >> 16; h1 *= 0x85EBCA6Bu;
+      } else if constexpr (ph == 5) {
+        h0 ^= h0 >> 13; h0 *= 0xC2B2AE35u; h1 ^= h1 >> 13; h1 *= 0xC2B2AE35u;
+      } else if constexpr (ph == 6) {
+        h0 ^= h0 >> 16; h1 ^= h1 >> 16;
+      } else if constexpr (ph == 7) {
+        u0 = ((h0 & 0xFFFFu) >= p.drop_thresh16 && o0 > 0.f) ? o0 * p.drop_scale : 0.f;
+        u1 = ((h0 >> 16) >= p.drop_thresh16 && o1 > 0.f) ? o1 * p.drop_scale : 0.f;
+      } else if constexpr (ph == 8) {
+        u2 = ((h1 & 0xFFFFu) >= p.drop_thresh16 && o2 > 0.f) ? o2 * p.drop_scale : 0.f;
+        u3 = ((h1 >> 16) >= p.drop_thresh16 && o3 > 0.f) ? o3 * p.drop_scale : 0.f;
+      } else {
+        up[2 * g] = pack_bf16x2(u0, u1); up[2 * g + 1] = pack_bf16x2(u2, u3);
+      }
+    } else if constexpr (rem == 4 * PH_UNIT) {
+      // lanes r / r + 32 hold channels {0-3, 8-11, ..} / {4-7, 12-15, ..} of one row -> 16-byte pieces
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          auto sw = __builtin_amdgcn_permlane32_swap(up[4 * h2 + d], up[4 * h2 + 2 + d], false, false);
+          up[4 * h2 + d] = sw[0]; up[4 * h2 + 2 + d] = sw[1];
+        }
+    } else {
+      if (ty >= 0) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        T* dst = reinterpret_cast<T*>(p.y_act) + (long long)p_b * p.ya_bs + (long long)ty * p.ldya + n0 + wave * 32 + 8 * hh;
+        *reinterpret_cast<u32x4*>(dst) = u32x4{up[0], up[1], up[2], up[3]};
+        *reinterpret_cast<u32x4*>(dst + 16) = u32x4{up[4], up[5], up[6], up[7]};
+      }
+    }
+  };
+
+  stage_a(tile_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < MW; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) pc[i][e] = 0;
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    const int buf = (tile - tile_begin) & 1;
+    int b, cls, t0;
+    decode(tile, b, cls, t0);
+    __syncthreads();                 // tile `tile` is in LDS for every wave; every wave is done with the other buffer
+    if (tile + 1 < tile_end) stage_a(tile + 1, buf ^ 1);
+
+    f32x16 acc[MW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    const unsigned abase = lds_base + (unsigned)buf * (unsigned)buf_bytes;
+    unsigned tap_base[NTAPS];
+#pragma unroll
+    for (int s = 0; s < NTAPS; ++s) {
+      const int ar = r + s * p.dil;
+      tap_base[s] = abase + ar * ROWB + ((hh ^ (ar & 15)) << 4);
+    }
+    auto frag_addr = [&](int q) -> unsigned { return tap_base[q / (KC / 16)] ^ (32u * (q % (KC / 16))); };
+    bf16x8 afr[2][MW];
+
+    // the MFMA pipeline of conv_ws_kernel with micro-step 4q + i of the pending epilogue behind MFMA (q, i).  (The
+    // first tile runs the micro-steps on an empty pending tile -- p_Tc = 0 suppresses its stores -- so that there is
+    // ONE copy of the loop: with two, the allocator no longer keeps the pinned weights in AccVGPRs.)
+    {
+      const unsigned ap0 = frag_addr(0);
+#pragma unroll
+      for (int i = 0; i < MW; ++i)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(afr[0][i]) : "v"(ap0), "n"(i * 32 * ROWB));
+    }
+    static_for<0, NSTEP>([&](auto Q) {
+      constexpr int q = decltype(Q)::value;
+      if constexpr (q + 1 < NSTEP) {
+        const unsigned ap = frag_addr(q + 1);
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(afr[(q + 1) & 1][i]) : "v"(ap), "n"(i * 32 * ROWB));
+        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      static_for<0, MW>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        if constexpr (q == 0) asm volatile("s_nop 4" : "+v"(acc[i]));
+        if constexpr (q / (KC / 16) < AGPR_TAPS)
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "a"(wfrag[q / (KC / 16)][q % (KC / 16)]), "v"(afr[q & 1][i]));
+        else
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(wfrag[q / (KC / 16)][q % (KC / 16)]), "v"(afr[q & 1][i]));
+        if constexpr (4 * q + i < PH_TILE) {
+          __builtin_amdgcn_sched_barrier(0);
+          epi(std::integral_constant<int, 4 * q + i>{});
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+    });
+    static_for<(NGAP < PH_TILE ? NGAP : PH_TILE), PH_TILE>(epi);   // micro-steps that did not fit behind this tile's MFMAs
+    // the hazard recogniser does not see MFMAs inside asm: let the last ones drain before VALU reads acc
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
+                 : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile has landed; older stores retired
+    // hand the tile over: y = bf16(acc + bias), packed
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) pc[i][e >> 1] = pack_bf16x2(acc[i][e] + bval[e], acc[i][e + 1] + bval[e + 1]);
+    p_b = b; p_cls = cls; p_t0 = t0;
+    p_Tc = (p.Tout - cls + rs - 1) / rs;
+    p_len = p.lens_out ? p.lens_out[b] : 0x7fffffff;
+  }
+  static_for<0, PH_TILE>(epi);                          // epilogue of the last tile
+}
+
 template <int NTAPS, int MODE>
 static void launch_ws_mode(const ConvArgs& p, const void* zero_page, dim3 grid, size_t lds, int tpw, int buf_bytes,
                            hipStream_t stream) {
@@ -930,7 +1161,11 @@ template <int NTAPS>
 static void launch_ws(const ConvArgs& p, const void* zero_page, dim3 grid, size_t lds, int tpw, int buf_bytes,
                       hipStream_t stream) {
   const bool y = p.y != nullptr, ao = p.act_out != 0, res = p.res != nullptr, ea = p.epi_act != 0;
-  if (!y && ao && !res && !ea) launch_ws_mode<NTAPS, 1>(p, zero_page, grid, lds, tpw, buf_bytes, stream);
+  static const bool no_pipe = getenv("SMT_CONV_NO_PIPE") != nullptr;
+  if (!y && ao && !res && !ea && !no_pipe) {
+    (void)hipFuncSetAttribute((const void*)conv_ws_pipe_kernel<NTAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    conv_ws_pipe_kernel<NTAPS><<<grid, WS_NT, lds, stream>>>(p, (const __bf16*)zero_page, tpw, buf_bytes);
+  } else if (!y && ao && !res && !ea) launch_ws_mode<NTAPS, 1>(p, zero_page, grid, lds, tpw, buf_bytes, stream);
   else if (y && !ao && res && ea) launch_ws_mode<NTAPS, 2>(p, zero_page, grid, lds, tpw, buf_bytes, stream);
   else launch_ws_mode<NTAPS, 0>(p, zero_page, grid, lds, tpw, buf_bytes, stream);
 }

@@ -279,7 +279,7 @@ def test_lds_dma_conv_kernel_matches_generic_kernel(k, dil):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("k,dil", [(3, 1), (5, 3), (7, 9), (9, 27)])
-@pytest.mark.parametrize("epi", ["plain", "res+actgrad+actout"])
+@pytest.mark.parametrize("epi", ["plain", "res+actgrad+actout", "actout-only", "res+actgrad"])
 def test_weight_stationary_conv_kernel_matches_generic_kernel(k, dil, epi):
     """The persistent weight-stationary kernel (weights in registers, double-buffered LDS-DMA activation tiles,
     dilation classes for dil >= 8) against the register-staged generic kernel on enough rows for it to be
@@ -300,14 +300,15 @@ def test_weight_stationary_conv_kernel_matches_generic_kernel(k, dil, epi):
         y = torch.zeros(b, t, c, device="cuda", dtype=torch.bfloat16)
         u = torch.zeros_like(y)
         wp = C._pack_fwd(w, torch.bfloat16, dma)
-        d = C._base_desc(x, y, lens, c, c, k, 1, dil, pad, t)
+        d = C._base_desc(x, None if epi == "actout-only" else y, lens, c, c, k, 1, dil, pad, t, t_y=t)
         d.w, d.bias = C._p(wp), C._p(bias)
         if dma:
             C._use_dma(d, wp)
         d.lens_out = C._p(lens)
-        if epi != "plain":
+        if epi.startswith("res+actgrad"):
             d.res, d.bs_res, d.ld_res = C._geom(res)
             C._set_act_grad(d, u_src, 1.111)
+        if "actout" in epi:
             C._set_act_out(d, u, [C.dropout_key(3, 5)], 6554, 1.0 / 0.9, c)
         names.append(C._kernel_of(d))
         C._launch(d, "t")
@@ -315,7 +316,7 @@ def test_weight_stationary_conv_kernel_matches_generic_kernel(k, dil, epi):
         outs.append((y, u))
     assert names == ["conv_gemm", "conv_ws"]
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    assert outs[0][0].float().abs().sum() > 0
+    assert (outs[0][1] if epi == "actout-only" else outs[0][0]).float().abs().sum() > 0
 
 
 @pytest.mark.gpu

@@ -18,13 +18,19 @@ def step(i):
 for i in range(2): step(i)
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     step(2)
     torch.cuda.synchronize()
-ka = prof.key_averages(group_by_stack_n=6)
-rows = [e for e in ka if e.key in ("aten::fill_", "aten::zero_", "aten::zeros", "aten::zeros_like", "aten::cat", "aten::copy_", "aten::empty_like")]
-rows.sort(key=lambda e: -e.count)
-for e in rows[:14]:
-    print(e.key, e.count)
-    for fr in e.stack[:6]:
-        print("     ", fr)
+evs = [e for e in prof.events() if e.name in ("aten::fill_", "aten::zero_", "aten::zeros", "aten::zeros_like", "aten::full")]
+import collections
+cnt = collections.Counter()
+for e in evs:
+    par = e.cpu_parent
+    chain = []
+    while par is not None and len(chain) < 4:
+        chain.append(par.name); par = par.cpu_parent
+    stack = [fr for fr in (e.stack or []) if "site-packages/torch" not in fr][:3]
+    cnt[(e.name, tuple(chain), tuple(stack))] += 1
+for (name, chain, stack), c in cnt.most_common(12):
+    print(c, name, "<-", " <- ".join(chain))
+    for fr in stack: print("      ", fr)

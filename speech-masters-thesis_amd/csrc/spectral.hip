@@ -19,17 +19,50 @@ namespace smt {
 struct cplx { float x, y; };
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 
-// Stockham radix-2; input in `a`, result pointer returned (a or b).  inverse => conjugate twiddles.
+// Stockham autosort FFT, radix-4 passes (plus one radix-2 pass when log2 N is odd): half the passes -- and barriers --
+// of a radix-2 transform; this kernel is bound by the LDS round trip + barrier per pass, not by bandwidth.
+// Input in `a`, result pointer returned (a or b).  tw[k] = exp(-2 pi i k / N), k < N/2; inverse => conjugate twiddles.
+template <int N>
+__device__ __forceinline__ cplx fft_twiddle(const cplx* __restrict__ tw, int idx, bool inverse) {
+  // exp(-2 pi i idx / N) for idx < N from the half table: e^{-i(pi + x)} = -e^{-ix}
+  cplx w = tw[idx & (N / 2 - 1)];
+  if (idx >= N / 2) { w.x = -w.x; w.y = -w.y; }
+  if (inverse) w.y = -w.y;
+  return w;
+}
+
 template <int N>
 __device__ __forceinline__ cplx* fft_lds(cplx* a, cplx* b, const cplx* __restrict__ tw, bool inverse) {
   cplx* in = a; cplx* out = b;
+  int ns = 1;
 #pragma unroll 1
-  for (int ns = 1; ns < N; ns <<= 1) {
+  for (; ns * 4 <= N; ns <<= 2) {
+    const int tw_stride = N / (4 * ns);
+    for (int j = threadIdx.x; j < N / 4; j += 256) {
+      const int k = j & (ns - 1);
+      const cplx u0 = in[j];
+      const cplx u1 = cmul(in[j + N / 4], fft_twiddle<N>(tw, k * tw_stride, inverse));
+      const cplx u2 = cmul(in[j + N / 2], fft_twiddle<N>(tw, 2 * k * tw_stride, inverse));
+      const cplx u3 = cmul(in[j + 3 * (N / 4)], fft_twiddle<N>(tw, 3 * k * tw_stride, inverse));
+      const cplx v0 = {u0.x + u2.x, u0.y + u2.y}, v1 = {u0.x - u2.x, u0.y - u2.y};
+      const cplx v2 = {u1.x + u3.x, u1.y + u3.y};
+      const cplx d = {u1.x - u3.x, u1.y - u3.y};
+      // forward: times -i, inverse: times +i
+      const cplx v3 = inverse ? cplx{-d.y, d.x} : cplx{d.y, -d.x};
+      const int j0 = ((j - k) << 2) + k;
+      out[j0] = {v0.x + v2.x, v0.y + v2.y};
+      out[j0 + ns] = {v1.x + v3.x, v1.y + v3.y};
+      out[j0 + 2 * ns] = {v0.x - v2.x, v0.y - v2.y};
+      out[j0 + 3 * ns] = {v1.x - v3.x, v1.y - v3.y};
+    }
+    __syncthreads();
+    cplx* t = in; in = out; out = t;
+  }
+  if (ns < N) {   // one radix-2 pass left (log2 N odd)
     const int tw_stride = N / (2 * ns);
     for (int j = threadIdx.x; j < N / 2; j += 256) {
       const int k = j & (ns - 1);
-      cplx w = tw[k * tw_stride];
-      if (inverse) w.y = -w.y;
+      const cplx w = fft_twiddle<N>(tw, k * tw_stride, inverse);
       const cplx u = in[j];
       const cplx v = cmul(in[j + N / 2], w);
       const int j0 = ((j - k) << 1) + k;

@@ -1477,12 +1477,17 @@ static bool conv_dma_eligible(const smt_conv_desc* d) {
 }
 
 // Plan of the LDS-DMA family for one conv: dilation classes, then weight-stationary / 256-row / 128-row tiles.
+// rows a dilation class must have for the decomposition to pay (tile quantisation wastes ceil(Tc/128)*128 - Tc rows)
+static int class_min_rows() {
+  static const int v = getenv("SMT_CLASS_MIN_ROWS") ? atoi(getenv("SMT_CLASS_MIN_ROWS")) : 128;
+  return v;
+}
 struct DmaPlan { bool ws; bool big; int buf_bytes; size_t lds; int tiles_per_wg; dim3 grid; };
 static bool plan_conv_dma(ConvArgs& p, DmaPlan& pl) {
   // Dilation classes (see conv_gemm_dma_kernel) for same-size convs whose padding is a multiple of a large
   // dilation, as long as a class still has enough rows to fill tiles.
   p.rs = 1;
-  if (p.dil >= 8 && p.taps > 1 && p.pad % p.dil == 0 && p.Tin == p.Tout && p.Tout / p.dil >= 512) {
+  if (p.dil >= 8 && p.taps > 1 && p.pad % p.dil == 0 && p.Tin == p.Tout && p.Tout / p.dil >= class_min_rows()) {
     p.rs = p.dil; p.pad /= p.dil; p.dil = 1;
   }
   const int tc_max = (p.Tout + p.rs - 1) / p.rs;

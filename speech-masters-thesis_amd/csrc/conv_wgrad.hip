@@ -543,14 +543,16 @@ static bool wgrad_shift_plan(const smt_conv_desc* d, ShiftPlan* pl) {
     return false;
   int rs = 1, pad = d->padding;
   if (d->dilation > 1) {
-    if (d->padding % d->dilation != 0 || d->t_out / d->dilation < 512) return false;
+    static const int min_rows = getenv("SMT_CLASS_MIN_ROWS") ? atoi(getenv("SMT_CLASS_MIN_ROWS")) : 128;
+    if (d->padding % d->dilation != 0 || d->t_out / d->dilation < min_rows) return false;
     rs = d->dilation; pad = d->padding / d->dilation;
   }
   if (pad < 0 || pad > d->taps - 1) return false;
   const long long tc_max = (d->t_out + rs - 1) / rs;
   const int tpi = (int)((tc_max + SH_R - 1) / SH_R);
   const long long ntiles = (long long)tpi * d->batch * rs;
-  if (ntiles < 512) return false;                       // small levels: the per-tap kernel wastes less
+  static const int min_tiles = getenv("SMT_SHIFT_MIN_TILES") ? atoi(getenv("SMT_SHIFT_MIN_TILES")) : 256;
+  if (ntiles < min_tiles) return false;                 // small levels: the per-tap kernel wastes less
   const int nco = d->c_out / 64, nci = d->c_in / 128;
   const long long chunks_target = std::max<long long>(8, 256 / (nco * nci));   // one workgroup per CU
   const int tpw = (int)((ntiles + chunks_target - 1) / chunks_target);

@@ -1482,6 +1482,11 @@ static int class_min_rows() {
   static const int v = getenv("SMT_CLASS_MIN_ROWS") ? atoi(getenv("SMT_CLASS_MIN_ROWS")) : 128;
   return v;
 }
+// tiles a launch must have for the persistent weight-stationary kernel (it loads the weight block once per workgroup)
+static int ws_min_tiles() {
+  static const int v = getenv("SMT_WS_MIN_TILES") ? atoi(getenv("SMT_WS_MIN_TILES")) : 512;
+  return v;
+}
 struct DmaPlan { bool ws; bool big; int buf_bytes; size_t lds; int tiles_per_wg; dim3 grid; };
 static bool plan_conv_dma(ConvArgs& p, DmaPlan& pl) {
   // Dilation classes (see conv_gemm_dma_kernel) for same-size convs whose padding is a multiple of a large
@@ -1498,7 +1503,7 @@ static bool plan_conv_dma(ConvArgs& p, DmaPlan& pl) {
     const size_t lds = 2 * (size_t)buf_bytes + 2 * WS_EPI;
     const int tpb = (tc_max + WS_BM - 1) / WS_BM;
     const long long ntiles = (long long)tpb * p.B * p.rs;
-    if (!no_ws && p.Cin == 128 && p.taps >= 3 && p.taps <= 9 && (p.taps & 1) && lds <= 160 * 1024 && ntiles >= 256 * 4) {
+    if (!no_ws && p.Cin == 128 && p.taps >= 3 && p.taps <= 9 && (p.taps & 1) && lds <= 160 * 1024 && ntiles >= ws_min_tiles()) {
       p.tiles_per_batch = tpb;
       const int nwg = 256;
       pl.ws = true; pl.big = false; pl.buf_bytes = buf_bytes; pl.lds = lds;

@@ -186,6 +186,16 @@ int smt_conv_k1_bwd(const void* dh, int64_t bs_dh, int ld_dh, const void* x, int
                     int64_t stride_out, int64_t stride_in, float* dbias, void* workspace, size_t workspace_bytes,
                     smt_stream_t stream);
 
+/* Fused backward of the 64 -> 64 1x1 gate convolution that closes a GatedHiFiBlock (bf16; resnet.py:238-241):
+ * dx[t,ci] = keep(t) * sum_co dy[t,co] * W[co][ci] (keep = t < lens[b]), dweight[co*stride_out + ci*stride_in] =
+ * sum_t dy[t,co] * g[t,ci] (g rows >= lens[b] read as 0), dbias[co] = sum_t dy[t,co].  dy / g / dx are [B,t,64] with
+ * explicit pitches; w_packed_bwd = smt_pack_weight(..) layout [ci][co], swizzle 0; zero_page >= 256 zero bytes. */
+size_t smt_conv_gate_bwd_workspace_bytes(int batch, int t);
+int smt_conv_gate_bwd(const void* dy, int64_t bs_dy, int ld_dy, const void* g, int64_t bs_g, int ld_g,
+                      const void* w_packed_bwd, void* dx, int64_t bs_dx, int ld_dx, const int* lens, int batch, int t,
+                      const void* zero_page, float* dweight, int64_t stride_out, int64_t stride_in, float* dbias,
+                      void* workspace, size_t workspace_bytes, smt_stream_t stream);
+
 /* sum_d tanh(t_d) * softmax_d(s_d) over `depth` branches laid side by side along the channel axis
  * (z[.., d*2w + c] = t_d, z[.., d*2w + w + c] = s_d) -- GatedHiFiBlock.forward, resnet.py:229-237. */
 int smt_gate_mix_fwd(const void* z, void* g, int dtype, int64_t rows, int width, int depth, int ld_z, int ld_g,

@@ -331,6 +331,19 @@ def _conv1x1_bwd(desc, dweight, s_out, s_in, dbias):
                                     N.stream_ptr()), "smt_conv1x1_bwd")
 
 
+def _conv_gate_bwd(dy, g, w_packed_bwd, dx, lens32, dweight, dbias):
+    """Fused data + weight gradient of the 64 -> 64 gate conv (smt_conv_gate_bwd): one pass over dy."""
+    lib = N.lib()
+    b, t = g.shape[0], g.shape[1]
+    ws = N.workspace.get(lib.smt_conv_gate_bwd_workspace_bytes(b, t), g.device)
+    (pdy, bsdy, lddy), (pg, bsg, ldg), (pdx, bsdx, lddx) = _geom(dy), _geom(g), _geom(dx)
+    rows = float(b) * t
+    with profiler.region("conv_gate_bwd", flops=4.0 * rows * 64 * 64, nbytes=rows * 3 * 64 * 2, bound="hbm", dtype="bf16"):
+        N.check(lib.smt_conv_gate_bwd(pdy, bsdy, lddy, pg, bsg, ldg, _p(w_packed_bwd), pdx, bsdx, lddx, _p(lens32), b, t,
+                                      _p(_zero_page(g.device)), _p(dweight), dweight.stride(0), dweight.stride(1),
+                                      _p(dbias), _p(ws), ws.numel(), N.stream_ptr()), "smt_conv_gate_bwd")
+
+
 def _conv_k1_bwd(dh, x, w_packed_bwd, res, dx, lens32, dweight, dbias):
     """Fused data + weight gradient of the 64 -> 512 K1 layer (smt_conv_k1_bwd): one pass over dh."""
     lib = N.lib()
@@ -706,11 +719,15 @@ class _GatedHiFi(torch.autograd.Function):
 
         # gate conv: dg = (dout . Wg^T) * mask ; dWg, dbg
         dg = torch.empty_like(g)
-        d = _dgrad_stride1(dout, _pack_bwd(wg, dt), dg, 1, 1, 0)
-        d.lens_out = _p(lens32)
-        _launch(d, "conv_dgrad", _conv_flops(d), _conv_bytes(d, x.element_size()))
         grads[6 * depth], grads[6 * depth + 1] = torch.empty_like(wg), f32(bg.shape)
-        _wgrad(_base_desc(g, dout, lens32, w, w, 1, 1, 1, 0, t), grads[6 * depth], w, 1, 1, [0], grads[6 * depth + 1])
+        if dt == torch.bfloat16 and w == 64:
+            # data gradient and weight gradient both read dout: one fused pass
+            _conv_gate_bwd(dout, g, _pack_bwd(wg, dt), dg, lens32, grads[6 * depth], grads[6 * depth + 1])
+        else:
+            d = _dgrad_stride1(dout, _pack_bwd(wg, dt), dg, 1, 1, 0)
+            d.lens_out = _p(lens32)
+            _launch(d, "conv_dgrad", _conv_flops(d), _conv_bytes(d, x.element_size()))
+            _wgrad(_base_desc(g, dout, lens32, w, w, 1, 1, 1, 0, t), grads[6 * depth], w, 1, 1, [0], grads[6 * depth + 1])
 
         dz = torch.empty_like(z)
         with profiler.region("gate_mix_bwd", nbytes=z.numel() * z.element_size() * 2.125, bound="hbm"):

@@ -36,6 +36,9 @@ _SIGNATURES = {
     "smt_conv1d_wgrad": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "smt_conv1x1_bwd_workspace_bytes": (c_size, [c_ptr]),
     "smt_conv1x1_bwd": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_size, c_ptr]),
+    "smt_conv_gate_bwd_workspace_bytes": (c_size, [c_int, c_int]),
+    "smt_conv_gate_bwd": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_int,
+                                  c_int, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_size, c_ptr]),
     "smt_conv_k1_bwd_workspace_bytes": (c_size, [c_int, c_int]),
     "smt_conv_k1_bwd": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64,
                                 c_int, c_ptr, c_int, c_int, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_size, c_ptr]),

@@ -529,3 +529,33 @@ def test_pack_cache_follows_in_place_weight_updates():
     changed = run()                                       # run() re-checks against torch with the NEW weights
     assert len(C._pack_cache.entries) == n_entries
     assert not torch.equal(first[0][0], changed[0][0]) and not torch.equal(first[0][1], changed[0][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,t", [(3, 700), (2, 20011), (1, 1)])
+def test_fused_gate_conv_backward_matches_separate_kernels(b, t):
+    """smt_conv_gate_bwd (one pass over dout) against the data-gradient conv it replaces (bit-identical: same MFMA
+    chain) and a float64 reference for the fp32 weight / bias gradients; ragged lens included."""
+    from smt_amd import convops as C
+    g_ = torch.Generator(device="cuda").manual_seed(19 * b + t)
+    c = 64
+    dout = torch.randn(b, t, c, device="cuda", generator=g_).to(torch.bfloat16)
+    gbig = torch.randn(b, t, 128, device="cuda", generator=g_).to(torch.bfloat16)
+    g = gbig[:, :, 64:128]                                    # channel slice: row pitch 128
+    w = torch.randn(c, c, 1, device="cuda", generator=g_) / c ** 0.5
+    lens = torch.tensor([t, t // 3, 1][:b], device="cuda", dtype=torch.int32)
+    wb = C._pack_bwd(w, torch.bfloat16)
+    dx_ref = torch.zeros(b, t, c, device="cuda", dtype=torch.bfloat16)
+    d = C._dgrad_stride1(dout, wb, dx_ref, 1, 1, 0)
+    d.lens_out = C._p(lens)
+    C._launch(d, "t")
+    dx = torch.zeros_like(dx_ref)
+    dw, db = torch.empty_like(w), torch.empty(c, device="cuda")
+    C._conv_gate_bwd(dout, g, wb, dx, lens, dw, db)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx_ref)
+    mask = (torch.arange(t, device="cuda")[None, :] < lens[:, None]).double()[:, :, None]
+    dw64 = torch.einsum("bto,bti->oi", dout.double(), g.double() * mask)
+    db64 = dout.double().sum((0, 1))
+    assert float((dw[:, :, 0].double() - dw64).abs().max()) <= 2e-6 * float(dw64.abs().max()) * (b * t) ** 0.5 + 1e-4
+    assert float((db.double() - db64).abs().max()) <= 2e-6 * float(db64.abs().max()) * (b * t) ** 0.5 + 1e-3

@@ -554,7 +554,11 @@ static bool wgrad_shift_plan(const smt_conv_desc* d, ShiftPlan* pl) {
   static const int min_tiles = getenv("SMT_SHIFT_MIN_TILES") ? atoi(getenv("SMT_SHIFT_MIN_TILES")) : 256;
   if (ntiles < min_tiles) return false;                 // small levels: the per-tap kernel wastes less
   const int nco = d->c_out / 64, nci = d->c_in / 128;
-  const long long chunks_target = std::max<long long>(8, 256 / (nco * nci));   // one workgroup per CU
+  // one workgroup per CU, but at least `min_tpw` tiles per workgroup: every workgroup leaves a (taps + 1) x 32 KiB slab
+  // that the reduce kernel reads back, which at the small levels would rival the operand traffic
+  static const int min_tpw = getenv("SMT_SHIFT_MIN_TPW") ? atoi(getenv("SMT_SHIFT_MIN_TPW")) : 1;
+  const long long chunks_target =
+      std::max<long long>(8, std::min<long long>(256 / (nco * nci), ntiles / std::max(1, min_tpw)));
   const int tpw = (int)((ntiles + chunks_target - 1) / chunks_target);
   pl->rs = rs; pl->pad = pad; pl->tiles_per_item = tpi; pl->tiles_per_wg = tpw;
   pl->n_chunks = (int)((ntiles + tpw - 1) / tpw); pl->nblk_co = nco; pl->nblk_ci = nci;

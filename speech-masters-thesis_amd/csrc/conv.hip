@@ -944,7 +944,7 @@ __global__ __launch_bounds__(WS_NT) void conv_ws_pipe_kernel(ConvArgs p, const _
   typedef __bf16 T;
   constexpr int EPV = 8, BM = WS_BM, BN = 128, KC = 128, NT = WS_NT, MW = BM / 32, ROWB = KC * 2;
   constexpr int NSTEP = NTAPS * (KC / 16), NGAP = NSTEP * MW;
-  constexpr int PH_UNIT = 10, PH_ROW = 4 * PH_UNIT + 2, PH_TILE = MW * PH_ROW;
+  constexpr int PH_UNIT = 12, PH_ROW = 4 * PH_UNIT + 2, PH_TILE = MW * PH_ROW;
   constexpr int AGPR_TAPS = NTAPS < 8 ? NTAPS : 8;
   static_assert(MW == 4, "four accumulators");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -1045,9 +1045,11 @@ __global__ __launch_bounds__(WS_NT) void conv_ws_pipe_kernel(ConvArgs p, const _
         h0 ^= h0 >> 16; h1 ^= h1 >> 16;
       } else if constexpr (ph == 7) {
         u0 = ((h0 & 0xFFFFu) >= p.drop_thresh16 && o0 > 0.f) ? o0 * p.drop_scale : 0.f;
-        u1 = ((h0 >> 16) >= p.drop_thresh16 && o1 > 0.f) ? o1 * p.drop_scale : 0.f;
       } else if constexpr (ph == 8) {
+        u1 = ((h0 >> 16) >= p.drop_thresh16 && o1 > 0.f) ? o1 * p.drop_scale : 0.f;
+      } else if constexpr (ph == 9) {
         u2 = ((h1 & 0xFFFFu) >= p.drop_thresh16 && o2 > 0.f) ? o2 * p.drop_scale : 0.f;
+      } else if constexpr (ph == 10) {
         u3 = ((h1 >> 16) >= p.drop_thresh16 && o3 > 0.f) ? o3 * p.drop_scale : 0.f;
       } else {
         up[2 * g] = pack_bf16x2(u0, u1); up[2 * g + 1] = pack_bf16x2(u2, u3);

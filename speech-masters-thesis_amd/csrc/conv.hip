@@ -663,7 +663,7 @@ __global__ __launch_bounds__(DMA_NT) void conv1x1_dma_kernel(ConvArgs p, const _
 //     only that back, so the epilogue operands need neither registers during the tap loop nor a barrier.
 // Measured motivation (tools/ablate_dma.sh): the streaming kernel spends as long waiting for HBM (tile in,
 // tile out) as it does in MFMAs, and with one workgroup per CU the two never overlap.
-constexpr int WS_AGPR_TAPS = 7;   // taps whose weights are pinned to AccVGPRs (7 x 32 = 224 of 256)
+constexpr int WS_AGPR_TAPS = 8;   // taps whose weights are pinned to AccVGPRs (8 x 32 = all 256)
 constexpr int WS_BM = 128, WS_NT = 256, WS_EPI = 128 * 256;   // rows per tile, threads, epilogue-operand tile bytes
 
 // MODE fixes the epilogue at compile time (straight-line code instead of ~85 branches in the unrolled epilogue, which

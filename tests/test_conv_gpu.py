@@ -559,3 +559,117 @@ def test_fused_gate_conv_backward_matches_separate_kernels(b, t):
     db64 = dout.double().sum((0, 1))
     assert float((dw[:, :, 0].double() - dw64).abs().max()) <= 2e-6 * float(dw64.abs().max()) * (b * t) ** 0.5 + 1e-4
     assert float((db.double() - db64).abs().max()) <= 2e-6 * float(db64.abs().max()) * (b * t) ** 0.5 + 1e-3
+
+
+@pytest.mark.gpu
+def test_full_size_linearity_of_the_dilated_conv_kernels():
+    """BASELINE.json's full size of the top level (B = 32, T = 72,704, 128 channels, k = 9, dilation 27): scaling the
+    input by a power of two scales a bias-free bf16 convolution and its weight gradient exactly (bit-for-bit), zero
+    input gives exactly the bias, and the weight gradient of a one-hot-row dy picks out the shifted input rows."""
+    from smt_amd import convops as C
+    g = torch.Generator(device="cuda").manual_seed(99)
+    b, t, c, k, dil = 32, 72704, 128, 9, 27
+    pad = (k - 1) * dil // 2
+    x = torch.randn(b, t, c, device="cuda", generator=g).to(torch.bfloat16)
+    w = torch.randn(c, c, k, device="cuda", generator=g) / (c * k) ** 0.5
+    bias = torch.randn(c, device="cuda", generator=g)
+    wp = C._pack_fwd(w, torch.bfloat16, True)
+
+    def conv(inp, with_bias):
+        y = torch.empty(b, t, c, device="cuda", dtype=torch.bfloat16)
+        d = C._base_desc(inp, y, None, c, c, k, 1, dil, pad, t)
+        C._use_dma(d, wp)
+        d.bias = C._p(bias) if with_bias else None
+        assert C._kernel_of(d) == "conv_ws"
+        C._launch(d, "t")
+        return y
+
+    y1 = conv(x, False)
+    y2 = conv(x * 2, False)
+    assert torch.equal(y2, y1 * 2)                                     # exact: every product and sum doubles
+    y0 = conv(torch.zeros_like(x), True)
+    assert torch.equal(y0, bias.to(torch.bfloat16).expand(b, t, c))
+    del y0, y2
+
+    dy = torch.randn(b, t, c, device="cuda", generator=g).to(torch.bfloat16)
+
+    def wgrad(inp, dout):
+        dw, db = torch.empty(c, c, k, device="cuda"), torch.empty(c, device="cuda")
+        C._wgrad(C._base_desc(inp, dout, None, c, c, k, 1, dil, pad, t), dw, c * k, k, 1, list(range(k)), db)
+        return dw, db
+
+    dw1, db1 = wgrad(x, dy)
+    dw2, db2 = wgrad(x * 2, dy)
+    assert torch.equal(dw2, dw1 * 2) and torch.equal(db2, db1)         # fp32 sums double exactly, db does not see x
+    # one-hot dy (row t0 of batch 3, channel 5 = 1): dW[5, :, s] = x[3, t0 + s*dil - pad, :]
+    t0 = 40000
+    hot = torch.zeros_like(dy)
+    hot[3, t0, 5] = 1
+    dwh, dbh = wgrad(x, hot)
+    torch.cuda.synchronize()
+    for s in range(k):
+        assert torch.equal(dwh[5, :, s], x[3, t0 + s * dil - pad].float())
+    assert float(dwh[:5].abs().max()) == 0 and float(dwh[6:].abs().max()) == 0 and float(dbh.sum()) == 1.0
+
+
+@pytest.mark.gpu
+def test_full_size_properties_of_the_fused_backward_kernels():
+    """Full top-level size (B = 32, T = 72,704): the fused K3 / K1 / gate backward kernels are linear in dy (a power-of-two
+    scale goes through bit-for-bit), zero dy gives zero weight gradients and passes the residual through unchanged."""
+    from smt_amd import convops as C
+    g = torch.Generator(device="cuda").manual_seed(123)
+    b, t = 32, 72704
+    bf = torch.bfloat16
+    # K3: 128 -> 128 behind relu+dropout
+    dz = torch.randn(b, t, 128, device="cuda", generator=g).to(bf)
+    u2 = torch.relu(torch.randn(b, t, 128, device="cuda", generator=g)).to(bf)
+    w3 = torch.randn(128, 128, 1, device="cuda", generator=g) / 128 ** 0.5
+    wb3 = C._pack_bwd(w3, bf, True)
+
+    def k3(dzz):
+        dx = torch.empty(b, t, 128, device="cuda", dtype=bf)
+        d = C._dgrad_stride1(dzz, wb3, dx, 1, 1, 0)
+        C._use_dma(d, wb3)
+        C._set_act_grad(d, u2, 1.0)
+        dw, db = torch.empty_like(w3), torch.empty(128, device="cuda")
+        C._conv1x1_bwd(d, dw, 128, 1, db)
+        return dx, dw, db
+
+    dx1, dw1, db1 = k3(dz)
+    dx2, dw2, db2 = k3(dz * 4)
+    assert torch.equal(dx2, dx1 * 4) and torch.equal(dw2, dw1 * 4) and torch.equal(db2, db1 * 4)
+    assert float((dx1.float().abs() * (u2 == 0)).max()) == 0                     # masked where the activation was off
+    del dx1, dx2, dz
+    # K1: 64 -> 512 with the block residual
+    dh = torch.randn(b, t, 512, device="cuda", generator=g).to(bf)
+    x = torch.randn(b, t, 64, device="cuda", generator=g).to(bf)
+    res = torch.randn(b, t, 64, device="cuda", generator=g).to(bf)
+    w1 = torch.randn(512, 64, 1, device="cuda", generator=g) / 8
+    wb1 = C._pack_bwd(w1, bf)
+
+    def k1(dhh):
+        dx = torch.empty_like(x)
+        dw, db = torch.empty_like(w1), torch.empty(512, device="cuda")
+        C._conv_k1_bwd(dhh, x, wb1, res, dx, None, dw, db)
+        return dx, dw, db
+
+    dxa, dwa, dba = k1(dh)
+    dxb, dwb, dbb = k1(dh * 2)
+    assert torch.equal(dwb, dwa * 2) and torch.equal(dbb, dba * 2)
+    dx0, dw0, db0 = k1(torch.zeros_like(dh))
+    assert torch.equal(dx0, res) and float(dw0.abs().max()) == 0 and float(db0.abs().max()) == 0
+    # gate: 64 -> 64
+    dout = torch.randn(b, t, 64, device="cuda", generator=g).to(bf)
+    gg = torch.randn(b, t, 64, device="cuda", generator=g).to(bf)
+    wg = torch.randn(64, 64, 1, device="cuda", generator=g) / 8
+    wbg = C._pack_bwd(wg, bf)
+
+    def gate(dd):
+        dx = torch.empty_like(gg)
+        dw, db = torch.empty_like(wg), torch.empty(64, device="cuda")
+        C._conv_gate_bwd(dd, gg, wbg, dx, None, dw, db)
+        return dx, dw, db
+
+    a, bq = gate(dout), gate(dout * 2)
+    torch.cuda.synchronize()
+    assert torch.equal(bq[0], a[0] * 2) and torch.equal(bq[1], a[1] * 2) and torch.equal(bq[2], a[2] * 2)

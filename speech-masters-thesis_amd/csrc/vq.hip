@@ -272,30 +272,52 @@ __global__ __launch_bounds__(256) void vq_finalize_kernel(const float* __restric
 
 // ---------------------------------------------------------------- rescore ---
 // Exact fp64 re-scoring of queued rows over ALL codes: d_j = sum_i (x_i - k_ji)^2 accumulated in index
-// order without fma contraction (== the numpy float64 loop of the oracle).  One workgroup per queued
-// row, grid-stride over the queue; thread t owns code (block*256 + t).  Codebook blocks are staged
-// through LDS ([256 codes][64 dims], pitch 65 floats) so that the global reads are coalesced 16-byte
-// accesses and every thread then walks ITS code's dims conflict-free.
+// order without fma contraction (== the numpy float64 loop of the oracle).  A workgroup takes up to RB queued
+// rows at a time; thread t owns code (block*256 + t) and scores it against all of them, so one pass of the
+// codebook through LDS ([256 codes][32 dims], pitch 33 floats: coalesced 16-byte global reads, conflict-free
+// per-code walks) serves RB rows -- with one row per workgroup the 512 KiB codebook was re-staged per row,
+// which made this kernel the largest part of smt_vq_forward on an untrained encoder (many near-tie rows).
+constexpr int VQ_RB = 8;
+template <int NR>
+__device__ __forceinline__ void vq_rescore_accum(const float* kr, const double (*xs)[256], int d0, int dn, double* acc) {
+  for (int i = 0; i < dn; ++i) {
+    const double kv = (double)kr[i];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+      const double df = __dsub_rn(xs[rr][d0 + i], kv);
+      acc[rr] = __dadd_rn(acc[rr], __dmul_rn(df, df));
+    }
+  }
+}
 __global__ __launch_bounds__(256) void vq_rescore_kernel(const float* __restrict__ x, const float* __restrict__ cb,
                                                          const float* __restrict__ row_mask, long long N, int K, int D,
                                                          const int* __restrict__ q_count, const int* __restrict__ q_rows,
                                                          long long* __restrict__ idx, float* __restrict__ min_dist,
                                                          float* __restrict__ x_d) {
-  constexpr int HB = 64, PITCH = 65;
-  __shared__ double xs[256];
+  constexpr int HB = 32, PITCH = 33, RB = VQ_RB;     // 33.8 KiB tile + 16 KiB of rows: three workgroups per CU
+  __shared__ double xs[RB][256];
   __shared__ float tile[256 * PITCH];
   __shared__ double red_d[256];
   __shared__ int red_i[256];
   const int n_q = *q_count;
   const int halves = (D + HB - 1) / HB;
-  for (int q = blockIdx.x; q < n_q; q += gridDim.x) {
-    const long long row = q_rows[q];
+  // rows per workgroup and pass: as few as keeps every workgroup busy, at most RB
+  const int rpw = max(1, min(RB, (n_q + (int)gridDim.x - 1) / (int)gridDim.x));
+  for (int q0 = blockIdx.x * rpw; q0 < n_q; q0 += gridDim.x * rpw) {
+    const int nr = min(rpw, n_q - q0);
     __syncthreads();
-    if (threadIdx.x < D) xs[threadIdx.x] = (double)x[row * D + threadIdx.x];
-    double bd = INFINITY;
-    int bi = 0x7fffffff;
+    for (int f = threadIdx.x; f < nr * D; f += 256) {
+      const int rr = f / D, i = f - rr * D;
+      xs[rr][i] = (double)x[(long long)q_rows[q0 + rr] * D + i];
+    }
+    double bd[RB];
+    int bi[RB];
+#pragma unroll
+    for (int rr = 0; rr < RB; ++rr) { bd[rr] = INFINITY; bi[rr] = 0x7fffffff; }
     for (int c0 = 0; c0 < K; c0 += 256) {
-      double acc = 0.0;
+      double acc[RB];
+#pragma unroll
+      for (int rr = 0; rr < RB; ++rr) acc[rr] = 0.0;
       for (int hf = 0; hf < halves; ++hf) {
         const int d0 = hf * HB, dn = min(HB, D - d0);          // dims [d0, d0 + dn), dn % 4 == 0
         __syncthreads();
@@ -309,33 +331,47 @@ __global__ __launch_bounds__(256) void vq_rescore_kernel(const float* __restrict
         }
         __syncthreads();
         const float* kr = &tile[threadIdx.x * PITCH];
-        for (int i = 0; i < dn; ++i) {
-          double df = __dsub_rn(xs[d0 + i], (double)kr[i]);
-          acc = __dadd_rn(acc, __dmul_rn(df, df));
+        switch (nr) {                                            // workgroup-uniform: straight-line code per row count
+          case 1: vq_rescore_accum<1>(kr, xs, d0, dn, acc); break;
+          case 2: vq_rescore_accum<2>(kr, xs, d0, dn, acc); break;
+          case 3: vq_rescore_accum<3>(kr, xs, d0, dn, acc); break;
+          case 4: vq_rescore_accum<4>(kr, xs, d0, dn, acc); break;
+          case 5: vq_rescore_accum<5>(kr, xs, d0, dn, acc); break;
+          case 6: vq_rescore_accum<6>(kr, xs, d0, dn, acc); break;
+          case 7: vq_rescore_accum<7>(kr, xs, d0, dn, acc); break;
+          default: vq_rescore_accum<8>(kr, xs, d0, dn, acc); break;
         }
       }
       const int code = c0 + threadIdx.x;
-      if (code < K && acc < bd) { bd = acc; bi = code; }        // increasing code order: lowest index on ties
+#pragma unroll
+      for (int rr = 0; rr < RB; ++rr)
+        if (code < K && acc[rr] < bd[rr]) { bd[rr] = acc[rr]; bi[rr] = code; }   // increasing code order: lowest index on ties
     }
-    red_d[threadIdx.x] = bd;
-    red_i[threadIdx.x] = bi;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (threadIdx.x < o) {
-        double od = red_d[threadIdx.x + o];
-        int oi = red_i[threadIdx.x + o];
-        if (od < red_d[threadIdx.x] || (od == red_d[threadIdx.x] && oi < red_i[threadIdx.x])) {
-          red_d[threadIdx.x] = od; red_i[threadIdx.x] = oi;
-        }
-      }
+#pragma unroll
+    for (int rr = 0; rr < RB; ++rr) {
+      if (rr >= nr) break;                                       // workgroup-uniform
       __syncthreads();
-    }
-    const int wi = red_i[0];
-    const float m = row_mask ? row_mask[row] : 1.f;
-    if (x_d && threadIdx.x < D) x_d[row * D + threadIdx.x] = cb[(size_t)wi * D + threadIdx.x] * m;
-    if (threadIdx.x == 0) {
-      idx[row] = wi;
-      min_dist[row] = (float)red_d[0];   // the exact distance, rounded once
+      red_d[threadIdx.x] = bd[rr];
+      red_i[threadIdx.x] = bi[rr];
+      __syncthreads();
+      for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+          double od = red_d[threadIdx.x + o];
+          int oi = red_i[threadIdx.x + o];
+          if (od < red_d[threadIdx.x] || (od == red_d[threadIdx.x] && oi < red_i[threadIdx.x])) {
+            red_d[threadIdx.x] = od; red_i[threadIdx.x] = oi;
+          }
+        }
+        __syncthreads();
+      }
+      const long long row = q_rows[q0 + rr];
+      const int wi = red_i[0];
+      const float m = row_mask ? row_mask[row] : 1.f;
+      if (x_d && threadIdx.x < D) x_d[row * D + threadIdx.x] = cb[(size_t)wi * D + threadIdx.x] * m;
+      if (threadIdx.x == 0) {
+        idx[row] = wi;
+        min_dist[row] = (float)red_d[0];   // the exact distance, rounded once
+      }
     }
   }
 }

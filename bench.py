@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: LJSpeech-shaped utterances/sec of the VQ-VAE train step.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N rank processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -31,7 +31,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3
 BF16_MFMA_PEAK_TFLOPS = 2500.0
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=10)
@@ -45,8 +45,11 @@ def parse():
     p.add_argument("--event_every", type=int, default=3,
                    help="bracket every native call with HIP events on every N-th timed step (events serialise the "
                         "kernels around them: ~4 %% of the step when every step is instrumented)")
-    p.add_argument("--cpu_clip_len", type=int, default=CLIP_LEN)
-    return p.parse_args()
+    p.add_argument("--cpu_clip_len", type=int, default=CLIP_LEN // 4,
+                   help="clip length of the bounded CPU-baseline sample (a quarter utterance keeps 3 + 5 steps near 30 s)")
+    p.add_argument("--no_fp32", action="store_true", help="skip the secondary fp32 (parity path) measurement")
+    p.add_argument("--fp32_steps", type=int, default=3)
+    return p.parse_args(argv)
 
 
 def make_config(args):
@@ -70,35 +73,91 @@ def synthetic_batches(n_batches, batch, length, rank, device):
 
 
 def cpu_baseline(args):
-    """The oracle (CPU restatement of the reference path, oracle/vqvae_oracle.py) timed on this
-    box's host cores on a bounded sample: one clip per step, same clip length and model config."""
+    """The oracle (CPU restatement of the reference path, oracle/vqvae_oracle.py) timed on this box's host cores on
+    a bounded sample, protocol of SURVEY 8(d) / BASELINE.md 3: torch.set_num_threads(os.cpu_count()), 3 warm-up +
+    5 timed train steps, median.  The sample is ONE clip of --cpu_clip_len samples per step (default a quarter
+    utterance, so the leg stays near 30 s); the rate is converted to full-length utterances/s by the sample ratio
+    (the conv stacks, which are the step, cost the same per sample at any length)."""
+    import statistics
     from oracle import vqvae_oracle as orc
     from utils import config as C
     mcfg = C.load(os.path.join(PKG, "configs/models", args.model + ".yaml")).model
     cfg = orc.VQVAEConfig.from_dict(mcfg.to_dict())
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
     threads = torch.get_num_threads()
     trainer = orc.OracleTrainer(cfg, seed=0)
     x = orc.synthetic_clip_batch(1, args.cpu_clip_len, 123)
     lens = torch.tensor([args.cpu_clip_len])
-    trainer.step(x, lens)  # warm-up (codebook init, allocator)
+    for _ in range(3):
+        trainer.step(x, lens)
     times = []
-    for _ in range(2):
+    for _ in range(5):
         t0 = time.perf_counter()
         trainer.step(x, lens)
         times.append(time.perf_counter() - t0)
-    best = min(times)
-    return {"value": 1.0 / best, "unit": "utterances/s", "cores": threads, "kind": "port",
-            "sample": f"oracle train step (fp32, torch-CPU, {threads} threads), batch 1 x {args.cpu_clip_len} samples, "
-                      f"min of 2 timed steps after 1 warm-up ({best:.1f} s/step)"}
+    med = statistics.median(times)
+    frac = args.cpu_clip_len / float(args.clip_len)
+    return {"value": frac / med, "unit": "utterances/s", "cores": cores, "threads": threads, "kind": "port",
+            "sample": f"oracle train step (fp32, torch-CPU), batch 1 x {args.cpu_clip_len} samples "
+                      f"({frac:.3f} of a {args.clip_len}-sample utterance), 3 warm-up + 5 timed steps, median "
+                      f"{med:.2f} s/step (min {min(times):.2f}, max {max(times):.2f}); value = {frac:.3f} / median"}
 
 
-def main():
-    args = parse()
+def launch_or_none(args, argv):
+    """`python bench.py --gpus N` with N > 1 outside torchrun: start N rank processes of this script (fresh
+    interpreters; this parent makes no HIP call) and return their exit code.  None = run in this process."""
+    from smt_amd import launcher
+    if launcher.under_launcher() or args.gpus <= 1:
+        return None
+    visible = torch.cuda.device_count()          # does not initialise the GPU on this image
+    if visible < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {visible} GPU(s) visible on this node", file=sys.stderr)
+        return 2
+    return launcher.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + list(argv))
+
+
+def timed_fp32(args, pool, device, note):
+    """Secondary measurement: the fp32 parity path (same model, same batch, compute_dtype fp32) for a few steps."""
+    from utils.commons import get_model, get_optimizer
+    from utils.train_utils import seed_all_rng
+    import train as trainlib
+    cfg = make_config(args)
+    cfg.model.compute_dtype = "fp32"
+    seed_all_rng(cfg.train.seed)
+    model, ema = get_model(cfg, device, 0)
+    optimizer, scheduler = get_optimizer(cfg, model)
+    model.train()
+
+    def step(i):
+        return trainlib.train_step(global_step=i, batch=pool[i % len(pool)], config=cfg, model=model, ema=ema,
+                                   optimizer=optimizer, scheduler=scheduler, device=device, rank=0, grad_sync=None)
+    step(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.fp32_steps):
+        loss_dict, _ = step(1 + i)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    note(f"fp32 parity path: {el / args.fp32_steps * 1e3:.1f} ms/step")
+    return {"value": args.batch * args.fp32_steps / el, "unit": "utterances/s", "ms_per_step": el / args.fp32_steps * 1e3,
+            "steps": args.fp32_steps, "warmup": 1, "dtype": "fp32", "loss": float(loss_dict["loss"].detach()),
+            "note": "same workload on the fp32 parity path (conv stacks on v_mfma_f32_32x32x2_f32)"}
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    rc = launch_or_none(args, argv)
+    if rc is not None:
+        sys.exit(rc)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs MI355X GPUs (no CPU fallback for the hot path)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
@@ -117,7 +176,7 @@ def main():
     grad_sync = None
     if world > 1:
         from smt_amd.dist import GradSync
-        grad_sync = GradSync(model.parameters())
+        grad_sync = GradSync(model.parameters(), timing=True)
     model.train()
 
     t_start = time.perf_counter()
@@ -139,6 +198,8 @@ def main():
         note(f"warm-up step {i} done")
     profiler.reset()
     profiler.enable(False)
+    if grad_sync is not None:
+        grad_sync.exposed_ms()            # drop the warm-up steps' events
     every = max(1, args.event_every)
     n_prof = 0
     if world > 1:
@@ -156,21 +217,30 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     profiler.enable(False)
+    per_rank_ms = [elapsed / args.steps * 1e3]
+    sync_ms = None
     if world > 1:
-        t = torch.tensor([elapsed], device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+        mine = torch.tensor([elapsed], device=device)
+        every_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every_rank, mine)
+        per_rank_ms = [t.item() / args.steps * 1e3 for t in every_rank]
+        elapsed = max(t.item() for t in every_rank)            # MAX over ranks
+        sync_ms = grad_sync.exposed_ms()
 
     if rank == 0:
         kernels = profiler.summary()
         m = cfg.model
         n_rows = args.batch * (args.clip_len // 128)
 
-        pmc = {}
-        pmc_path = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc_path):
-            with open(pmc_path) as f:
-                pmc = json.load(f)
+        pmc, pmc_source = {}, None
+        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            pmc_path = os.path.join(REPO, "profiles", name)
+            if os.path.exists(pmc_path):
+                with open(pmc_path) as f:
+                    pmc = json.load(f)
+                pmc_source = f"profiles/{name} (stored rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this " \
+                             "benchmark, tools/collect_profiles.sh; not re-measured in this run)"
+                break
 
         def group(prefixes, label, bound, dtype, pmc_key=None):
             recs = [k for k in kernels if any(k["name"] == q or k["name"].startswith(q + ":") or
@@ -191,16 +261,16 @@ def main():
                     "frac": achieved / peak, "launches_per_step": launches / max(1, n_prof),
                     "avg_us": total_us / launches, "ms_per_step": total_us * 1e-3 / max(1, n_prof),
                     "alg_flops_per_launch": flops / launches, "alg_bytes_per_launch": nbytes / launches,
-                    "traffic": traffic}
+                    "traffic": traffic, "traffic_source": pmc_source if traffic is not None else None}
 
         dt = "bf16" if m.get("compute_dtype") == "bf16" else "f32"
         # dominant kernel by time: the weight-stationary implicit-GEMM conv kernel (dilated 128->128 convs, fwd + dgrad)
-        roofline = group({"conv_ws"}, "smt::conv_ws_kernel (dilated 128->128 convs, forward + data gradient)",
+        roofline = group({"conv_ws", "conv_ws_pipe"}, "smt::conv_ws_kernel / conv_ws_pipe_kernel (dilated 128->128 convs, forward + data gradient)",
                          "mfma", dt, "conv_ws_kernel")
         if roofline is None:   # fp32 configuration: everything runs on the generic kernel
             roofline = group({"conv_gemm"}, "smt::conv_gemm_kernel", "mfma", dt, "conv_gemm_kernel")
         extra_rooflines = {
-            "conv_wgrad": group({"conv_wgrad"}, "smt::conv_wgrad_shift_kernel / conv_wgrad{,_dma}_kernel + reduce", "mfma",
+            "conv_wgrad": group({"conv_wgrad", "conv_wgrad_shift", "conv_wgrad_dma"}, "smt::conv_wgrad_shift_kernel / conv_wgrad{,_dma}_kernel + reduce", "mfma",
                                 dt, "conv_wgrad_shift_kernel"),
             "conv1x1_bwd": group({"conv1x1_bwd"}, "smt::conv1x1_bwd_kernel (fused K3 backward, HBM-bound)", "hbm", dt,
                                  "conv1x1_bwd_kernel"),
@@ -228,7 +298,12 @@ def main():
             "value": args.batch * world * args.steps / elapsed,
             "unit": "utterances/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "world_size": dist.get_world_size() if world > 1 else 1,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_per_rank": per_rank_ms,
+            "grad_sync_exposed_ms_per_step": sync_ms,
+            "native_launches_per_step": sum(k["launches"] for k in kernels) / max(1, n_prof),
+            "native_kernel_ms_per_step": sum(k["total_ms"] for k in kernels) / max(1, n_prof),
             "host_enqueue_ms_per_step": host_elapsed / args.steps * 1e3,
             "kernel_event_steps": n_prof,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -244,10 +319,14 @@ def main():
             "kernels": kernels,
         }
         note(f"timed region done: {line['value']:.2f} utt/s, {line['ms_per_step']:.1f} ms/step")
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_fp32 and m.get("compute_dtype") == "bf16":
+            del model, optimizer, scheduler, ema
+            torch.cuda.empty_cache()
+            line["fp32"] = timed_fp32(args, pool, device, note)
+        if world == 1 and not args.no_cpu_baseline:       # rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(args)
             note("cpu baseline done")
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -152,7 +152,7 @@ typedef struct smt_conv_desc {
 } smt_conv_desc;
 int smt_conv1d_ntc(const smt_conv_desc* desc, smt_stream_t stream);
 /* Name of the kernel smt_conv1d_ntc dispatches this descriptor to ("conv_gemm", "conv_gemm_dma", "conv_ws",
- * "conv1x1_dma", "conv1x1_fold", "conv_k1act"): for profilers and tests; no device work. */
+ * "conv_ws_pipe", "conv1x1_dma", "conv1x1_fold", "conv_k1act"): for profilers and tests; no device work. */
 const char* smt_conv1d_kernel_name(const smt_conv_desc* desc);
 
 /* Weight (+ bias) gradient of the same convolution:
@@ -164,6 +164,9 @@ size_t smt_conv1d_wgrad_workspace_bytes(const smt_conv_desc* desc);
 int smt_conv1d_wgrad(const smt_conv_desc* desc, float* dweight, int64_t stride_out, int64_t stride_in,
                      int64_t stride_tap, const int* tap_map, float* dbias, void* workspace,
                      size_t workspace_bytes, smt_stream_t stream);
+/* Name of the kernel smt_conv1d_wgrad runs for this descriptor ("conv_wgrad_shift", "conv_wgrad_dma", "conv_wgrad");
+ * no device work. */
+const char* smt_conv1d_wgrad_kernel_name(const smt_conv_desc* desc);
 
 /* Fused backward of a bf16 128 -> 128 1x1 convolution whose forward input was u = relu(dropout(h)) (K3 of
  * GatedHiFiBlock, resnet.py:218-227): one pass over dy and u yields the masked data gradient AND the weight / bias

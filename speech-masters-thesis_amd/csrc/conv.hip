@@ -1754,7 +1754,8 @@ extern "C" const char* smt_conv1d_kernel_name(const smt_conv_desc* d) {
     case K_1X1: return "conv1x1_dma";
     case K_FOLD: return "conv1x1_fold";
     case K_K1ACT: return "conv_k1act";
-    case K_WS: return "conv_ws";
+    case K_WS:   // same rule as launch_ws: the activated-output-only epilogue has the pipelined variant
+      return (!d->y && d->act_out && !d->res && !d->act_grad && !getenv("SMT_CONV_NO_PIPE")) ? "conv_ws_pipe" : "conv_ws";
     case K_DMA: return "conv_gemm_dma";
     default: return "conv_gemm";
   }

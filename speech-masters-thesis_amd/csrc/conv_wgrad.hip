@@ -790,6 +790,18 @@ static int wgrad_group(const smt_conv_desc* d, float* dweight, int64_t stride_ou
                              cib, stride_out, stride_in, stride_tap, tap_map, stream);
 }
 
+extern "C" const char* smt_conv1d_wgrad_kernel_name(const smt_conv_desc* d) {
+  if (!d) return "";
+  ShiftPlan pl;
+  if (wgrad_shift_plan(d, &pl)) return "conv_wgrad_shift";
+  const smt_conv_desc g = wgrad_group_desc(d, 0, std::min(WG_GROUP, d->taps));
+  const int rows_x = 127 * g.stride + (g.taps - 1) * (wgrad_rs(&g) > 1 ? 1 : g.dilation) + 1;
+  const size_t lds_dma = 2 * ((size_t)128 * 128 + (size_t)((rows_x + 3) & ~3) * 256);
+  const bool dma = g.dtype == SMT_BF16 && wgrad_cib(&g) == 128 && g.stride == 1 && g.zero_page && g.c_in % 128 == 0 &&
+                   g.c_out % 64 == 0 && g.out_stride == 1 && g.out_offset == 0 && lds_dma <= 160 * 1024;
+  return dma ? "conv_wgrad_dma" : "conv_wgrad";
+}
+
 extern "C" int smt_conv1d_wgrad(const smt_conv_desc* d, float* dweight, int64_t stride_out, int64_t stride_in,
                                 int64_t stride_tap, const int* tap_map, float* dbias, void* workspace,
                                 size_t workspace_bytes, smt_stream_t stream_) {

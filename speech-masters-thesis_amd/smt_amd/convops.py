@@ -312,7 +312,7 @@ def _wgrad(desc, dweight, s_out, s_in, s_tap, tap_map, dbias):
     ws = N.workspace.get(ws_bytes, dweight.device)
     arr = (ctypes.c_int * len(tap_map))(*tap_map)
     dtype = "bf16" if desc.dtype == SMT_BF16 else "f32"
-    name = "conv_wgrad" + ("_" + _tag(desc) if profiler.DETAIL else "")
+    name = lib.smt_conv1d_wgrad_kernel_name(ctypes.byref(desc)).decode() + ("_" + _tag(desc) if profiler.DETAIL else "")
     with profiler.region(name, flops=_conv_flops(desc), bound="mfma", dtype=dtype):
         N.check(lib.smt_conv1d_wgrad(ctypes.byref(desc), _p(dweight), s_out, s_in, s_tap, arr, _p(dbias), _p(ws),
                                      ws.numel(), N.stream_ptr()), "smt_conv1d_wgrad")

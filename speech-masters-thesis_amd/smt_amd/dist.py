@@ -20,10 +20,15 @@ def broadcast_module(module, src=0):
 
 
 class GradSync:
-    def __init__(self, params, bucket_bytes=8 << 20, group=None):
+    def __init__(self, params, bucket_bytes=8 << 20, group=None, always_reduce=False, timing=False):
+        """``always_reduce``: register the hooks and issue the collectives even in a world of one rank (exercises the
+        asynchronous RCCL path on a single GPU).  ``timing``: bracket finish() with events on the current stream;
+        ``exposed_ms()`` is then the part of the gradient exchange that backward did not hide."""
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.reduce = dist.is_initialized() and (self.world > 1 or always_reduce)
+        self.timing, self._events = timing, []
         total = sum(p.numel() for p in self.params)
         device = self.params[0].device
         self.flat = torch.zeros(total, dtype=torch.float32, device=device)
@@ -42,7 +47,7 @@ class GradSync:
             self._close_bucket(start, offset, pending)
         self._handles = []
         self._attach_views()
-        if self.world > 1:
+        if self.reduce:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
 
@@ -73,9 +78,13 @@ class GradSync:
 
     def finish(self):
         """Wait for the in-flight buckets and turn the sums into means."""
-        if self.world == 1:
+        if not self.reduce:
             return
         launched = len(self._handles)
+        ev = None
+        if self.timing and self.flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for h in self._handles:
             h.wait()
         self._handles = []
@@ -84,4 +93,18 @@ class GradSync:
             for b in self.buckets:
                 if b["ready"] != b["count"]:
                     dist.all_reduce(self.flat[b["start"]:b["end"]], op=dist.ReduceOp.SUM, group=self.group)
-        self.flat.mul_(1.0 / self.world)
+        if self.world > 1:
+            self.flat.mul_(1.0 / self.world)
+        if ev is not None:
+            ev[1].record()
+            self._events.append(ev)
+
+    def exposed_ms(self, reset=True):
+        """Mean time per step the stream spent in finish() (waiting for bucket all-reduces + the 1/world scale)."""
+        if not self._events:
+            return None
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self._events) / len(self._events)
+        if reset:
+            self._events = []
+        return ms

@@ -33,6 +33,7 @@ _SIGNATURES = {
     "smt_conv1d_ntc": (c_int, [c_ptr, c_ptr]),
     "smt_conv1d_kernel_name": (ctypes.c_char_p, [c_ptr]),
     "smt_conv1d_wgrad_workspace_bytes": (c_size, [c_ptr]),
+    "smt_conv1d_wgrad_kernel_name": (ctypes.c_char_p, [c_ptr]),
     "smt_conv1d_wgrad": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "smt_conv1x1_bwd_workspace_bytes": (c_size, [c_ptr]),
     "smt_conv1x1_bwd": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_size, c_ptr]),

@@ -88,7 +88,9 @@ def _rccl_worker(rank, world, port, tmp):
         seed_all_rng(7)
         model, ema = get_model(cfg, torch.device("cuda", 0), 0)
         opt, sched = get_optimizer(cfg, model)
-        sync = GradSync(model.parameters(), bucket_bytes=64 << 10) if distributed else None
+        # always_reduce: hooks + asynchronous bucket all-reduces are issued on the nccl (= RCCL) backend even though the
+        # world has one rank, so the stream-ordered wait() path the multi-GPU bench relies on is the one exercised
+        sync = GradSync(model.parameters(), bucket_bytes=64 << 10, always_reduce=True, timing=True) if distributed else None
         model.train()
         losses = []
         for step in range(3):
@@ -100,6 +102,7 @@ def _rccl_worker(rank, world, port, tmp):
             losses.append(loss_dict["loss"].item())
         params = torch.cat([p.detach().reshape(-1).cpu() for p in model.parameters()])
         if distributed:
+            assert sync.reduce and len(sync.buckets) > 2 and sync.exposed_ms() is not None
             dist.destroy_process_group()
         return torch.tensor(losses), params
 

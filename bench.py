@@ -45,8 +45,8 @@ def parse(argv=None):
     p.add_argument("--event_every", type=int, default=3,
                    help="bracket every native call with HIP events on every N-th timed step (events serialise the "
                         "kernels around them: ~4 %% of the step when every step is instrumented)")
-    p.add_argument("--cpu_clip_len", type=int, default=CLIP_LEN // 4,
-                   help="clip length of the bounded CPU-baseline sample (a quarter utterance keeps 3 + 5 steps near 30 s)")
+    p.add_argument("--cpu_clip_len", type=int, default=CLIP_LEN // 2,
+                   help="clip length of the bounded CPU-baseline sample (half an utterance keeps 3 + 5 steps near 20-30 s)")
     p.add_argument("--no_fp32", action="store_true", help="skip the secondary fp32 (parity path) measurement")
     p.add_argument("--fp32_steps", type=int, default=3)
     return p.parse_args(argv)
@@ -72,18 +72,31 @@ def synthetic_batches(n_batches, batch, length, rank, device):
     return out
 
 
+def usable_cpus():
+    """CPUs this process may really use: the scheduler affinity capped by the cgroup CPU quota (a GPU box shows 256
+    logical CPUs but grants one GPU's share, 16: more threads than that are throttled -- 128 threads ran 9x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(args):
     """The oracle (CPU restatement of the reference path, oracle/vqvae_oracle.py) timed on this box's host cores on
-    a bounded sample, protocol of SURVEY 8(d) / BASELINE.md 3: torch.set_num_threads(os.cpu_count()), 3 warm-up +
-    5 timed train steps, median.  The sample is ONE clip of --cpu_clip_len samples per step (default a quarter
-    utterance, so the leg stays near 30 s); the rate is converted to full-length utterances/s by the sample ratio
-    (the conv stacks, which are the step, cost the same per sample at any length)."""
+    a bounded sample, protocol of SURVEY 8(d) / BASELINE.md 3: one thread per usable core, 3 warm-up + 5 timed train
+    steps, median.  The sample is ONE clip of --cpu_clip_len samples per step (default half an utterance, so the leg
+    stays near 20-30 s); the rate is converted to full-length utterances/s by the sample ratio (the conv stacks, which
+    are the step, cost the same per sample at any length)."""
     import statistics
     from oracle import vqvae_oracle as orc
     from utils import config as C
     mcfg = C.load(os.path.join(PKG, "configs/models", args.model + ".yaml")).model
     cfg = orc.VQVAEConfig.from_dict(mcfg.to_dict())
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     torch.set_num_threads(cores)
     threads = torch.get_num_threads()
     trainer = orc.OracleTrainer(cfg, seed=0)
@@ -98,7 +111,8 @@ def cpu_baseline(args):
         times.append(time.perf_counter() - t0)
     med = statistics.median(times)
     frac = args.cpu_clip_len / float(args.clip_len)
-    return {"value": frac / med, "unit": "utterances/s", "cores": cores, "threads": threads, "kind": "port",
+    return {"value": frac / med, "unit": "utterances/s", "cores": cores, "threads": threads,
+            "logical_cpus_visible": os.cpu_count(), "kind": "port",
             "sample": f"oracle train step (fp32, torch-CPU), batch 1 x {args.cpu_clip_len} samples "
                       f"({frac:.3f} of a {args.clip_len}-sample utterance), 3 warm-up + 5 timed steps, median "
                       f"{med:.2f} s/step (min {min(times):.2f}, max {max(times):.2f}); value = {frac:.3f} / median"}

@@ -314,7 +314,7 @@ def test_weight_stationary_conv_kernel_matches_generic_kernel(k, dil, epi):
         C._launch(d, "t")
         torch.cuda.synchronize()
         outs.append((y, u))
-    assert names == ["conv_gemm", "conv_ws"]
+    assert names == ["conv_gemm", "conv_ws_pipe" if epi == "actout-only" else "conv_ws"]
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert (outs[0][1] if epi == "actout-only" else outs[0][0]).float().abs().sum() > 0
 

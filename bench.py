@@ -300,13 +300,20 @@ def main(argv=None):
                                  "conv1x1_dma_kernel"),
             "conv_gemm": group({"conv_gemm"}, "smt::conv_gemm_kernel (register-staged generic path)", "mfma", dt,
                                "conv_gemm_kernel"),
-            "vq_forward": group({"vq_forward"}, "smt_vq_forward (mean, prep, score, finalize, rescore, reduce)", "hbm",
-                                "f32", "vq_forward"),
+            "vq_forward": group({"vq_forward"}, "smt_vq_forward (search, candidates, exact, reduce)", "hbm", "bf16",
+                                "vq_forward"),
             "vq_ema_accumulate": group({"vq_ema_accumulate"}, "smt::vq_ema_accumulate_kernel", "hbm", "f32"),
             "gate_mix": group({"gate_mix_fwd", "gate_mix_bwd"}, "smt::gate_mix_{fwd,bwd}_kernel", "hbm", dt, "gate_mix"),
             "stft_loss": group({"stft_loss_fwd", "stft_loss_bwd"}, "smt::stft_loss_{fwd,bwd}_kernel", "hbm", "f32"),
         }
         extra_rooflines = {k: v for k, v in extra_rooflines.items() if v is not None}
+        if "vq_forward" in extra_rooflines:
+            # the north-star kernel against BOTH bounds: HBM by algorithmic bytes (above) and the bf16 matrix pipe by the
+            # 3 x 2 N K D FLOP of its filter (its intensity, ~1500 FLOP/B at K = 1024, puts it on the MFMA side)
+            v = extra_rooflines["vq_forward"]
+            tf = v["alg_flops_per_launch"] / v["avg_us"] * 1e-6
+            v["mfma"] = {"achieved": tf, "peak": profiler.PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                         "frac": tf / profiler.PEAK_TFLOPS["bf16"]}
         line = {
             "metric": "LJSpeech utterances/sec per VQ-VAE train step",
             "value": args.batch * world * args.steps / elapsed,

@@ -36,33 +36,44 @@ const char* smt_last_error(void);
 int smt_abi_version(void);
 
 /* ------------------------------------------------------------------ VQ ---- */
+/* Per-codebook derived data of the nearest-code search (mean, centred bf16-pair split of the codes, -|k~|^2/2,
+ * max |k~|^2), kept in a caller-owned persistent buffer so that it is rebuilt only when the codebook changes:
+ * smt_vq_ema_apply refreshes it in the same call that rewrites the codebook; call smt_vq_prepare after any other
+ * write to `codebook` (initialisation, checkpoint load). */
+size_t smt_vq_prep_bytes(int k_bins, int dim);
+int smt_vq_prepare(const float* codebook, int k_bins, int dim, void* prep, size_t prep_bytes, smt_stream_t stream);
+
 /* BottleneckBlock.quantize + dequantize (models/vqvae/bottleneck.py:126-145)
  * and the per-row terms of the commit loss / fit metric (:140, :194).
  *
  *   x        [n_rows, dim]  f32, encoder output rows (NTC flattening, :92-98)
  *   codebook [k_bins, dim]  f32 (buffer `k`)
+ *   prep     the buffer smt_vq_prepare / smt_vq_ema_apply filled for THIS codebook content, or NULL (then it is
+ *            rebuilt inside the call, in the workspace).  It also carries the call's queue counter (zero between
+ *            calls): one forward at a time per prep buffer.
  *   row_mask [n_rows]       f32 0/1 or NULL (= all ones)
  * outputs
  *   idx      [n_rows] int64  exact argmin_j ||x - k_j||^2, lowest j on ties
  *   min_dist [n_rows] f32    ||x - k_idx||^2
  *   x_d      [n_rows, dim]   k[idx] * row_mask   (may be NULL)
  *   sums     [4] f32: {sum_all min_dist, sum_masked min_dist, sum mask,
- *                      number of rows that needed fp64 re-scoring}
+ *                      number of rows that needed exact (fp64) re-scoring}
  * dim in {32, 64, 128}; k_bins >= 1. */
 size_t smt_vq_forward_workspace_bytes(int64_t n_rows, int k_bins, int dim);
-int smt_vq_forward(const float* x, const float* codebook, const float* row_mask,
+int smt_vq_forward(const float* x, const float* codebook, void* prep, const float* row_mask,
                    int64_t n_rows, int k_bins, int dim,
                    int64_t* idx, float* min_dist, float* x_d, float* sums,
                    void* workspace, size_t workspace_bytes, smt_stream_t stream);
 
 /* Backward of the straight-through estimator + commit loss
- * (bottleneck.py:194-201):  dx = dy*mask*st_scale + g_commit * 2 (x - x_d) mask / (sum_mask * dim)
+ * (bottleneck.py:194-201):  dx = dy*mask + g_commit * 2 (x - x_d) mask / (sum_mask * dim)
+ *   x_d       [n_rows, dim] the x_d written by smt_vq_forward (= k[idx] on unmasked rows; masks are 0/1)
  *   dy        [n_rows, dim] grad of the (masked) quantised output, or NULL
  *   g_commit  [1] device scalar: upstream grad of the commit loss, or NULL
  *   sums      the `sums` written by smt_vq_forward (reads sums[2]) */
-int smt_vq_backward(const float* x, const float* x_d_unmasked_codebook, const int64_t* idx,
-                    const float* row_mask, const float* dy, const float* g_commit, const float* sums,
-                    int64_t n_rows, int dim, float* dx, smt_stream_t stream);
+int smt_vq_backward(const float* x, const float* x_d, const float* row_mask, const float* dy,
+                    const float* g_commit, const float* sums, int64_t n_rows, int dim, float* dx,
+                    smt_stream_t stream);
 
 /* Codebook EMA statistics, BottleneckBlock.update_k (bottleneck.py:64-68):
  * _k_sum = onehot @ x, _k_elem = onehot.sum(-1) over UNMASKED rows.
@@ -70,13 +81,14 @@ int smt_vq_backward(const float* x, const float* x_d_unmasked_codebook, const in
 int smt_vq_ema_accumulate(const float* x, const int64_t* idx, const float* row_mask,
                           int64_t n_rows, int k_bins, int dim, float* stats, smt_stream_t stream);
 
-/* bottleneck.py:78-90: EMA mix, dead-code revival from k_rand, metrics.
+/* bottleneck.py:78-90: EMA mix, dead-code revival from k_rand, metrics; refreshes `prep` for the new codebook.
  *   stats   as above (after the cross-rank SUM, :74-75)
  *   k_rand  [k_bins, dim] revival candidates (rank 0's, :73)
- *   metrics [4] f32: {entropy, used_curr, usage, dk} */
+ *   metrics [4] f32: {entropy, used_curr, usage, dk}
+ *   prep    smt_vq_prep_bytes(k_bins, dim) bytes (its previous content is not read) */
 int smt_vq_ema_apply(float* codebook, float* k_sum, float* k_elem, const float* stats,
                      const float* k_rand, float mu, float threshold, int k_bins, int dim,
-                     float* metrics, smt_stream_t stream);
+                     float* metrics, void* prep, size_t prep_bytes, smt_stream_t stream);
 
 
 /* ------------------------------------------------------------ conv stack ---- */

@@ -6,388 +6,617 @@
 //
 // Index semantics (oracle/vqvae_oracle.py: vq_argmin_exact): idx = the exact
 // argmin_j ||x - k_j||^2 of the fp32 inputs, lowest j on ties.  Implementation:
-//   1. vq_score   filter scores on the matrix cores (bf16-pair split of the fp32 operands,
-//                 3 x v_mfma_f32_32x32x16_bf16 per k-step), per row best + runner-up per 128-code slice;
-//   2. vq_finalize merges the slices; a row whose best/runner-up gap is inside the
-//                 rigorous fp32 round-off bound is queued, every other row is final;
-//   3. vq_rescore re-scores queued rows over ALL codes in fp64 (index order, no
-//                 contraction) -- the oracle's arithmetic;
-//   4. vq_reduce  fixed-order sums (deterministic commit / fit).
+//   0. prepare     (only when the codebook changes: smt_vq_prepare / smt_vq_ema_apply) codebook mean, centred bf16-pair
+//                  split of the codes, -|k~|^2/2, max |k~|^2 -- kept in a persistent `prep` buffer;
+//   1. vq_search   one workgroup sweeps ALL codes for its 64 rows on the matrix cores (3 x v_mfma_f32_32x32x16_bf16 per
+//                  k-step on the bf16-pair split of the fp32 operands = a FILTER score); best / runner-up never leave
+//                  registers; rows whose gap clears the rigorous round-off bound are finished in the same kernel
+//                  (idx, min_dist, x_d), the others are queued with their threshold best - 2 err;
+//   2. vq_candidates  queued rows only: the same MFMA sweep (code range split over workgroups) collects every code whose
+//                  filter score reaches the row's threshold -- the exact argmin is provably among them;
+//   3. vq_exact    scores just those in fp64, index order, no contraction (the oracle's arithmetic), lowest index on
+//                  ties; a row with too many candidates (degenerate codebooks) scans ALL codes the same way;
+//   4. vq_reduce   fixed-order sums (deterministic commit / fit).
 // The [N, K] distance matrix is never materialised.
+#include <algorithm>
+
 #include "smt_common.h"
+
+#ifndef VQ_ABL
+#define VQ_ABL 0      // timing experiments (tools/ablate_vq.sh, results invalid): 1 no MFMAs, 2 no re-staging of the codebook,
+#endif                // 4 no best/runner-up folding, 8 no epilogue, 16 phase timestamps (tools/vq_phases.py), 32 no fragment reads
 
 namespace smt {
 
-constexpr int VQ_ROWS_PER_WG = 128;   // 4 waves x 32 rows
-constexpr int VQ_SLICE = 128;         // codes per workgroup (4 chunks of 32)
+#if VQ_ABL & 16     // phase timestamps of vq_search_kernel (100 MHz wall clock), tools/ablate_vq.sh only
+__device__ long long vq_dbg[8192 * 6];
+#define VQ_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) vq_dbg[blockIdx.x * 6 + (k)] = wall_clock64(); } while (0)
+#else
+#define VQ_STAMP(k) do { } while (0)
+#endif
+
+constexpr int VQ_MAXRG = 5;           // 32-row MFMA column groups per workgroup of the search kernel (two waves each)
+constexpr int VQ_SSUP = 128;          // codes staged per step of the search kernel: two 32-code chunks per wave
+constexpr int VQ_CSUP = 64;           // ... of the candidates kernel: one chunk for each of its two waves
+constexpr int VQ_KPAD = 256;          // the prep pads the codebook to a multiple of this (two search steps)
 constexpr int VQ_CHUNK = 32;
+constexpr int VQ_SPLITS = 8;          // code-range splits of the candidate sweep (one workgroup each)
+constexpr int VQ_CAPS = 4;            // candidate codes kept per queued row and split
+constexpr int VQ_PART = 8;            // codes per partial column sum (prepare)
 
-// ---------------------------------------------------------------- prep ------
-// Distances are translation invariant, so the fp32 scoring pass runs on data centred at the codebook
-// mean mu: trained encoders emit rows with a large common offset, and the round-off bound that
-// decides which rows need fp64 re-scoring scales with the NORMS of the operands, not their spread.
-// mu[i] = mean_j k[j][i] (one thread per dimension, index order).
-__global__ __launch_bounds__(1024) void vq_mean_kernel(const float* __restrict__ cb, int K, int D,
-                                                       float* __restrict__ mu) {
-  __shared__ float part[1024];
-  const int parts = 1024 / D;                     // D in {32, 64, 128}
-  const int i = threadIdx.x % D, pt = threadIdx.x / D;
-  float s = 0.f;
-  for (int j = pt; j < K; j += parts) s += cb[(size_t)j * D + i];   // fixed order per part
-  part[threadIdx.x] = s;
-  __syncthreads();
-  if (pt == 0) {
-    float t = 0.f;
-    for (int q = 0; q < parts; ++q) t += part[q * D + i];            // parts combined in index order
-    mu[i] = t / (float)K;
-  }
-}
-// kc[j] = k[j] - mu, stored as the bf16 pair (kh, kl);  khalf[j] = 0.5 * |kc[j]|^2 (fp32, index order per lane then wave tree);
-// kmax2 = max_j |kc[j]|^2.  One wave per code.
-__global__ __launch_bounds__(256) void vq_prep_kernel(const float* __restrict__ cb, const float* __restrict__ mu,
-                                                      int K, int D, __bf16* __restrict__ kh, __bf16* __restrict__ kl,
-                                                      float* __restrict__ khalf, unsigned* __restrict__ kmax2_bits) {
-  int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  int lane = threadIdx.x & 63;
-  if (wave >= K) return;
-  float s = 0.f;
-  for (int i = lane; i < D; i += 64) {
-    float v = cb[(size_t)wave * D + i] - mu[i];
-    const __bf16 hi = (__bf16)v;                       // v = hi + lo + eps, |eps| <= 2^-18 |v|
-    kh[(size_t)wave * D + i] = hi;
-    kl[(size_t)wave * D + i] = (__bf16)(v - (float)hi);
-    s = fmaf(v, v, s);
-  }
-  s = wave_sum(s);
-  if (lane == 0) {
-    khalf[wave] = 0.5f * s;
-    atomicMax(kmax2_bits, __float_as_uint(s));  // s >= 0: uint order == float order
-  }
-}
-
-// ---------------------------------------------------------------- score -----
-// Workgroup = 4 waves = 128 rows x one 128-code slice.  The codebook is the MFMA A operand (code on the
-// row index i), x the B operand (row on the column index j = lane & 31), so every lane owns ONE x row
-// and sees 16 codes per chunk in its accumulator registers: the running best / runner-up is pure in-lane
-// work.  Arithmetic: each fp32 operand is split into a bf16 pair (v = hi + lo + eps, |eps| <= 2^-18 |v|)
-// and x.k is evaluated as kh.xh + kh.xl + kl.xh on v_mfma_f32_32x32x16_bf16 with fp32 accumulation --
-// 3 bf16 MFMAs (16x the fp32-MFMA rate each) replace 8 fp32 MFMAs.  The score is only a FILTER: its
-// error bound (vq_finalize) decides which rows are re-scored exactly, so the index semantics stay exact.
 typedef __bf16 vq_bf16x8 __attribute__((ext_vector_type(8)));
 
+// ---------------------------------------------------------------- prepare ---
+// Distances are translation invariant, so the filter runs on data centred at the codebook mean mu: trained encoders
+// emit rows with a large common offset, and the round-off bound that decides which rows need exact re-scoring scales
+// with the NORMS of the operands, not their spread.  Column sums: per-part in index order, parts in index order.
+struct VqPrep {
+  float* mu;          // [D]
+  float* nkhalf;      // [Kpad]   -0.5 |k~_j|^2, -3e38 for the padding codes j >= K
+  unsigned* kmax2;    // max_j |k~_j|^2 (float bits); kmax2[32] = number of queued rows of the forward in flight (zero between calls)
+  __bf16* kh;         // [Kpad][D] high halves of k~ = k - mu (zero rows for padding)
+  __bf16* kl;         // [Kpad][D] low halves
+  float* part;        // [ceil(K / VQ_PART)][D] partial column sums
+  double* dkpart;     // [ceil(K / VQ_PART)]    partial sums of (k_new - k_old)^2 (EMA apply)
+  int kpad, nparts;
+};
+static size_t vq_prep_layout(int K, int D, void* base, VqPrep* w) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return (char*)base + o; };
+  const int kpad = (K + VQ_KPAD - 1) / VQ_KPAD * VQ_KPAD, nparts = (K + VQ_PART - 1) / VQ_PART;
+  char* p;
+  p = take((size_t)D * 4);            if (w) w->mu = (float*)p;
+  p = take((size_t)kpad * 4);         if (w) w->nkhalf = (float*)p;
+  p = take(256);                      if (w) w->kmax2 = (unsigned*)p;
+  p = take((size_t)kpad * D * 2);     if (w) w->kh = (__bf16*)p;
+  p = take((size_t)kpad * D * 2);     if (w) w->kl = (__bf16*)p;
+  p = take((size_t)nparts * D * 4);   if (w) w->part = (float*)p;
+  p = take((size_t)nparts * 8);       if (w) w->dkpart = (double*)p;
+  if (w) { w->kpad = kpad; w->nparts = nparts; }
+  return off;
+}
+
+// part[p][i] = sum of k[j][i] over the codes j of part p (index order)
+__global__ __launch_bounds__(128) void vq_colsum_kernel(const float* __restrict__ cb, int K, int D, float* __restrict__ part) {
+  const int i = threadIdx.x;
+  if (i >= D) return;
+  const int j0 = blockIdx.x * VQ_PART;
+  float s = 0.f;
+  for (int j = j0; j < min(K, j0 + VQ_PART); ++j) s += cb[(size_t)j * D + i];
+  part[(size_t)blockIdx.x * D + i] = s;
+}
+
+// Single workgroup: mu from the partial column sums; with `cnt` also the metrics of update_k (bottleneck.py:85-90),
+// all reductions in fixed order.
+__global__ __launch_bounds__(1024) void vq_mu_kernel(const float* __restrict__ part, int nparts, int K, int D,
+                                                     float* __restrict__ mu, unsigned* __restrict__ kmax2_bits,
+                                                     const float* __restrict__ cnt, const float* __restrict__ k_elem,
+                                                     const double* __restrict__ dkpart, float threshold,
+                                                     float* __restrict__ metrics) {
+  __shared__ double sh[16];
+  __shared__ double bc;
+  auto block_sum = [&](double v) -> double {
+    v = wave_sum_d(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+      bc = t;
+    }
+    __syncthreads();
+    return bc;
+  };
+  if ((int)threadIdx.x < D) {
+    float t = 0.f;
+#pragma unroll 16
+    for (int p = 0; p < nparts; ++p) t += part[(size_t)p * D + threadIdx.x];   // index order; 16 loads in flight
+    mu[threadIdx.x] = t / (float)K;
+  }
+  if (threadIdx.x == 0) { kmax2_bits[0] = 0u; kmax2_bits[32] = 0u; }     // + the queue counter of smt_vq_forward
+  if (!cnt) return;                                        // workgroup-uniform
+  double tot = 0.0;
+  for (int j = threadIdx.x; j < K; j += blockDim.x) tot += cnt[j];
+  const float total = (float)block_sum(tot);
+  double ent = 0.0, used = 0.0, usage_n = 0.0, dk2 = 0.0;
+  for (int j = threadIdx.x; j < K; j += blockDim.x) {
+    const float c = cnt[j];
+    const float prob = c / total;
+    ent += -(double)(prob * logf(fmaxf(prob, 1e-5f)));
+    used += (c >= threshold) ? 1.0 : 0.0;
+    usage_n += (k_elem[j] >= threshold) ? 1.0 : 0.0;       // k_elem already holds the mixed value
+  }
+  for (int p = threadIdx.x; p < nparts; p += blockDim.x) dk2 += dkpart[p];
+  ent = block_sum(ent);
+  used = block_sum(used);
+  usage_n = block_sum(usage_n);
+  dk2 = block_sum(dk2);
+  if (threadIdx.x == 0) {
+    metrics[0] = (float)ent;
+    metrics[1] = (float)used;
+    metrics[2] = (float)usage_n;
+    metrics[3] = (float)(sqrt(dk2) / sqrt((double)K * D));
+  }
+}
+
+// Position of dim i of code j inside its [D] row of the kh / kl tiles: rows are NOT padded (they are copied to LDS by
+// linear LDS-DMA), so the 16-byte chunk index is XORed with the row index instead -- the 32 lanes of an MFMA A-fragment
+// read (32 consecutive codes, same chunk) then fall into 16 different 16-byte bank groups.
+__host__ __device__ __forceinline__ int vq_swz(int j, int D) { return (j / (128 / D)) & (D / 8 - 1); }
+
+// k~[j] = k[j] - mu as the bf16 pair (kh, kl) (v = hi + lo + eps, |eps| <= 2^-18 |v|), chunk-swizzled; nkhalf[j] =
+// -0.5 |k~[j]|^2 (fp32, index order per lane then wave tree); kmax2 = max_j |k~[j]|^2.  One wave per code, 16 codes per
+// workgroup (one atomicMax per workgroup); padding codes get zero rows and -inf.
+__global__ __launch_bounds__(1024) void vq_split_kernel(const float* __restrict__ cb, const float* __restrict__ mu, int K,
+                                                        int Kpad, int D, __bf16* __restrict__ kh, __bf16* __restrict__ kl,
+                                                        float* __restrict__ nkhalf, unsigned* __restrict__ kmax2_bits) {
+  __shared__ float wmax[16];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int code = blockIdx.x * 16 + wave;
+  float s = 0.f;
+  if (code < Kpad) {
+    const int sw = vq_swz(code, D);
+    for (int i = lane; i < D; i += 64) {
+      const float v = code < K ? cb[(size_t)code * D + i] - mu[i] : 0.f;
+      const __bf16 hi = (__bf16)v;
+      const size_t o = (size_t)code * D + 8 * ((i >> 3) ^ sw) + (i & 7);
+      kh[o] = hi;
+      kl[o] = (__bf16)(v - (float)hi);
+      s = fmaf(v, v, s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) nkhalf[code] = code < K ? -0.5f * s : -3.0e38f;   // padding: never the best, still a finite float
+  }
+  if (lane == 0) wmax[wave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float m = 0.f;
+    for (int w = 0; w < 16; ++w) m = fmaxf(m, wmax[w]);
+    atomicMax(kmax2_bits, __float_as_uint(m));  // m >= 0: uint order == float order
+  }
+}
+
+// ---------------------------------------------------------------- search ----
+// The codebook is the MFMA A operand (code on the row index i), x the B operand (row on the column index j = lane & 31),
+// so every lane owns ONE x row per column group and sees 16 codes per chunk in its accumulator registers: the running
+// best / runner-up is pure in-lane work.  Each fp32 operand is split into a bf16 pair and x~.k~ is evaluated as
+// kl.xh + kh.xl + kh.xh with fp32 accumulation on top of -|k~|^2/2 -- 3 bf16 MFMAs (16x the fp32-MFMA rate each)
+// instead of 8 fp32 MFMAs.  The score is only a FILTER: its error bound (vq_filter_err) decides which rows are
+// re-scored exactly, so the index semantics stay exact.
+//
+// Shape: 2 waves, 64 rows.  Each wave keeps BOTH 32-row column groups of the tile in registers (bf16 pairs of its
+// share of the rows) and takes one of the two 32-code chunks of every staged 64-code step, so one A fragment read from
+// LDS feeds 6 MFMAs and a workgroup stages the whole codebook exactly once for its 64 rows.  LDS: two stages of
+// [hi | lo][64][D + 8] bf16 + 64 floats.
+template <int D, int SUP> struct VqGeom {
+  static constexpr int NS = D / 16;                       // k-steps per chunk
+  static constexpr int TILE_BYTES = SUP * D * 2;          // one staged tile (hi or lo)
+  static constexpr int NDMA = TILE_BYTES / 1024;          // 1-KiB LDS-DMA wave-instructions per tile
+  static constexpr int BUF_BYTES = 2 * TILE_BYTES + SUP * 4;
+};
+
+__device__ __forceinline__ void vq_dma16(const void* gsrc, void* lds_dst_wave_base) {
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,
+                                   (void __attribute__((address_space(3)))*)lds_dst_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void vq_dma4(const void* gsrc, void* lds_dst_wave_base) {
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,
+                                   (void __attribute__((address_space(3)))*)lds_dst_wave_base, 4, 0, 0);
+}
+// Stage step `sc` (SUP codes: hi tile, lo tile, -|k~|^2/2) into `buf` with LDS-DMA, no register round trip: the nw
+// waves of the workgroup issue the 1-KiB pieces in turn.  The data has landed after every issuing wave's
+// `s_waitcnt vmcnt(0)` + a barrier.
+template <int D, int SUP>
+__device__ __forceinline__ void vq_stage(const __bf16* kh, const __bf16* kl, const float* nkhalf, int sc, char* buf,
+                                         int nw, int wave, int lane) {
+  using G = VqGeom<D, SUP>;
+  if ((VQ_ABL & 2) && sc > 1) return;
+  for (int q = wave; q < 2 * G::NDMA; q += nw) {
+    const int which = q / G::NDMA, piece = q % G::NDMA;
+    const __bf16* src = (which ? kl : kh) + (size_t)sc * SUP * D + piece * 512 + lane * 8;
+    vq_dma16(src, buf + which * G::TILE_BYTES + piece * 1024);
+  }
+  if (wave == nw - 1) {
+#pragma unroll
+    for (int i = 0; i < SUP / 64; ++i) vq_dma4(nkhalf + sc * SUP + 64 * i + lane, buf + 2 * G::TILE_BYTES + 256 * i);
+  }
+}
+__device__ __forceinline__ void vq_stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// this lane's share of row `row` (dims 16 s + 8 h .. + 7 for every k-step s), centred and split; returns its share of
+// |x~|^2.  All loads are issued before the first use (callers pass a row index that is always in range).
 template <int D>
-__global__ __launch_bounds__(256) void vq_score_kernel(const float* __restrict__ x, const __bf16* __restrict__ kh,
-                                                       const __bf16* __restrict__ kl, const float* __restrict__ mu,
-                                                       const float* __restrict__ khalf, long long N, int K, int S,
-                                                       float* __restrict__ p_best, int* __restrict__ p_idx,
-                                                       float* __restrict__ p_second) {
-  constexpr int NS = D / 16;                       // k-steps per chunk
-  constexpr int LDW = D + 8;                       // +16 B pad: conflict-free ds_read_b128
-  constexpr int V_PER_TILE = VQ_CHUNK * D / 8;     // 16-byte vectors in one staged 32-code tile (hi or lo)
-  constexpr int STAGE = (2 * V_PER_TILE + 255) / 256;
-  __shared__ __attribute__((aligned(16))) __bf16 lds[2][2][VQ_CHUNK * LDW];   // [buffer][hi|lo]
+__device__ __forceinline__ float vq_load_row(const float* __restrict__ x, const float* __restrict__ mu, long long row,
+                                             int h, vq_bf16x8* xh, vq_bf16x8* xl) {
+  constexpr int NS = D / 16, HB = NS < 4 ? NS : 4;           // k-steps per batch of loads (bounds the live registers)
+  float xx = 0.f;
+#pragma unroll
+  for (int s0 = 0; s0 < NS; s0 += HB) {
+    f32x4 v[HB][2], m[HB][2];
+#pragma unroll
+    for (int s = 0; s < HB; ++s) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(x + row * D + 16 * (s0 + s) + 8 * h);
+      const f32x4* msrc = reinterpret_cast<const f32x4*>(mu + 16 * (s0 + s) + 8 * h);
+      v[s][0] = src[0]; v[s][1] = src[1]; m[s][0] = msrc[0]; m[s][1] = msrc[1];
+    }
+#pragma unroll
+    for (int s = 0; s < HB; ++s) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float c = v[s][e >> 2][e & 3] - m[s][e >> 2][e & 3];
+        const __bf16 hi = (__bf16)c;
+        xh[s0 + s][e] = hi;
+        xl[s0 + s][e] = (__bf16)(c - (float)hi);
+        xx = fmaf(c, c, xx);
+      }
+    }
+  }
+  return xx;
+}
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = lane & 31, h = lane >> 5;
-  const int tile = blockIdx.x / S, slice = blockIdx.x % S;
-  const long long row = (long long)tile * VQ_ROWS_PER_WG + wave * 32 + j;
-  const int code0 = slice * VQ_SLICE;
-  const int nchunk = min(VQ_SLICE / VQ_CHUNK, (K - code0 + VQ_CHUNK - 1) / VQ_CHUNK);
+// Error of the filter score against the exact acc = x~.k~ - |k~|^2/2 on the centred operands (norms are the centred
+// ones, Cauchy-Schwarz turns sums of products into norm products):
+//   bf16-pair split, three of the four partial products kept:  <= 3.01 * 2^-18 |x~| |k~|
+//   fp32 accumulation of 3D exact products + the initial term:  <= 1.05 (3D+2) 2^-24 (|x~||k~| + |k~|^2/2)
+//   fp32 rounding of khalf and of the centring x - mu, k - mu:  <= 2^-24 ((D+2)|k~|^2/2 + (|x~| + |k~|)^2)
+//   position tag in the 4 low mantissa bits of a score (vq_search_kernel):   <= 2^-19 (|x~||k~| + |k~|^2/2)
+// with |k~| <= |k~|max; a factor 1.25 of slack covers the MFMA's internal summation order and the fp32 rounding of xx.
+__device__ __forceinline__ float vq_filter_err(float xx, float kmax2, int D) {
+  const float xk = sqrtf(xx * kmax2);
+  const float u24 = 5.9604645e-8f;
+  return 1.25f * (3.01f * 64.f * u24 * xk + (1.05f * (float)(3 * D + 2) + 32.f) * u24 * (xk + 0.5f * kmax2) +
+                  u24 * (0.5f * (float)(D + 2) * kmax2 + xx + 2.f * xk + kmax2));
+}
 
-  // this lane's share of its x row, centred and split: dims 16 s + 8 h .. + 7 for every k-step s
-  vq_bf16x8 xh[NS], xl[NS];
+// One 32-code chunk against NG column groups: acc[g] = -|k~|^2/2 + sum_s (kl.xh + kh.xl + kh.xh), small terms first.
+template <int D, int SUP, int NG>
+__device__ __forceinline__ void vq_chunk_scores(const char* buf, int chunk, int j, int h, const vq_bf16x8 (*xh)[D / 16],
+                                                const vq_bf16x8 (*xl)[D / 16], f32x16* acc) {
+  using G = VqGeom<D, SUP>;
+  constexpr int NS = D / 16;
+  const float* nk = reinterpret_cast<const float*>(buf + 2 * G::TILE_BYTES) + chunk * VQ_CHUNK + 4 * h;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(nk + 8 * q);       // codes 8 q + 4 h + e of the chunk
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      acc[g][4 * q + 0] = v.x; acc[g][4 * q + 1] = v.y; acc[g][4 * q + 2] = v.z; acc[g][4 * q + 3] = v.w;
+    }
+  }
+  const int rowi = chunk * VQ_CHUNK + j, sw = vq_swz(rowi, D);
+  const char* ah = buf + rowi * (2 * D);
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
-    if (row < N) {
-      const f32x4* src = reinterpret_cast<const f32x4*>(x + row * D + 16 * s + 8 * h);
-      const f32x4* msrc = reinterpret_cast<const f32x4*>(mu + 16 * s + 8 * h);
-      v0 = src[0] - msrc[0];
-      v1 = src[1] - msrc[1];
-    }
+    const int so = (VQ_ABL & 32) ? 0 : s;
+    const vq_bf16x8 fh = *reinterpret_cast<const vq_bf16x8*>(ah + 16 * ((2 * so + h) ^ sw));
+    const vq_bf16x8 fl = *reinterpret_cast<const vq_bf16x8*>(ah + G::TILE_BYTES + 16 * ((2 * so + h) ^ sw));
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float v = e < 4 ? v0[e & 3] : v1[e & 3];
-      const __bf16 hi = (__bf16)v;
-      xh[s][e] = hi;
-      xl[s][e] = (__bf16)(v - (float)hi);
-    }
-  }
-
-  f32x4 stage[STAGE];
-  auto load_chunk = [&](int c) {
-#pragma unroll
-    for (int r = 0; r < STAGE; ++r) {
-      const int f = threadIdx.x + 256 * r;                 // [hi tile vectors | lo tile vectors]
-      const int which = f / V_PER_TILE, g = f % V_PER_TILE;
-      const int code = g / (D / 8), c8 = g % (D / 8);
-      const int gcode = code0 + c * VQ_CHUNK + code;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (f < 2 * V_PER_TILE && gcode < K)
-        v = *reinterpret_cast<const f32x4*>((which ? kl : kh) + (size_t)gcode * D + 8 * c8);
-      stage[r] = v;
-    }
-  };
-  auto store_chunk = [&](int buf) {
-#pragma unroll
-    for (int r = 0; r < STAGE; ++r) {
-      const int f = threadIdx.x + 256 * r;
-      const int which = f / V_PER_TILE, g = f % V_PER_TILE;
-      const int code = g / (D / 8), c8 = g % (D / 8);
-      if (f < 2 * V_PER_TILE) *reinterpret_cast<f32x4*>(&lds[buf][which][code * LDW + 8 * c8]) = stage[r];
-    }
-  };
-
-  float best = -INFINITY, second = -INFINITY;
-  int bidx = 0x7fffffff;
-
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
-  for (int c = 0; c < nchunk; ++c) {
-    const int buf = c & 1;
-    if (c + 1 < nchunk) load_chunk(c + 1);
-    const int cbase = code0 + c * VQ_CHUNK;
-    // accumulator starts at -0.5*|k_i|^2 so that acc = x.k_i - 0.5|k_i|^2 (argmax == argmin distance)
-    f32x16 acc;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        int code = cbase + 8 * g + 4 * h + e;
-        acc[4 * g + e] = (code < K) ? -khalf[code] : 0.f;
+    for (int g = 0; g < NG; ++g) {
+      if (!(VQ_ABL & 1)) {
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, xh[g][s], acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, xl[g][s], acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, xh[g][s], acc[g], 0, 0, 0);
       }
     }
-    const __bf16* ah = &lds[buf][0][j * LDW + 8 * h];
-    const __bf16* al = &lds[buf][1][j * LDW + 8 * h];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const vq_bf16x8 fh = *reinterpret_cast<const vq_bf16x8*>(ah + 16 * s);
-      const vq_bf16x8 fl = *reinterpret_cast<const vq_bf16x8*>(al + 16 * s);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, xh[s], acc, 0, 0, 0);   // small terms first
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, xl[s], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, xh[s], acc, 0, 0, 0);
-    }
-    // in-lane running best / runner-up; codes visited in increasing order, strict '>' keeps
-    // the lowest index among equal scores
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int code = cbase + 8 * (r >> 2) + 4 * h + (r & 3);
-      float v = (code < K) ? acc[r] : -INFINITY;
-      if (v > best) {
-        second = best; best = v; bidx = code;
-      } else if (v > second) {
-        second = v;
-      }
-    }
-    if (c + 1 < nchunk) store_chunk(buf ^ 1);
-    __syncthreads();
   }
-  // merge the two lane halves of a row (same row, disjoint codes)
-  float ob = __shfl_xor(best, 32, 64), os = __shfl_xor(second, 32, 64);
-  int oi = __shfl_xor(bidx, 32, 64);
+}
+
+// top-2 merge of (best, second, idx) with another candidate triple; equal scores keep the lower index (the gap is then
+// zero and the row is re-scored exactly anyway)
+__device__ __forceinline__ void vq_merge(float& best, float& second, int& bidx, float ob, float os, int oi) {
   if (ob > best || (ob == best && oi < bidx)) {
     second = fmaxf(best, os); best = ob; bidx = oi;
   } else {
     second = fmaxf(second, ob);
   }
-  if (h == 0 && row < N) {
-    size_t o = (size_t)row * S + slice;
-    p_best[o] = best; p_idx[o] = bidx; p_second[o] = second;
-  }
 }
 
-// ---------------------------------------------------------------- finalize --
-// One wave per row: merge slices, test the gap against the round-off bound, and
-// for final rows write idx / min_dist / x_d.  Ambiguous rows go to the queue.
-__global__ __launch_bounds__(256) void vq_finalize_kernel(const float* __restrict__ x, const float* __restrict__ cb,
-                                                          const float* __restrict__ mu,
-                                                          const float* __restrict__ row_mask,
-                                                          const unsigned* __restrict__ kmax2_bits,
-                                                          const float* __restrict__ p_best, const int* __restrict__ p_idx,
-                                                          const float* __restrict__ p_second, long long N, int D, int S,
-                                                          long long* __restrict__ idx, float* __restrict__ min_dist,
-                                                          float* __restrict__ x_d, int* __restrict__ q_count,
-                                                          int* __restrict__ q_rows) {
-  const int lane = threadIdx.x & 63;
-  const long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (row >= N) return;
-  const float* xr = x + row * D;
-  float xv[4];
-  float xx = 0.f;
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    int i = lane + 64 * u;
-    xv[u] = (i < D) ? xr[i] : 0.f;
-    const float xc = (i < D) ? xv[u] - mu[i] : 0.f;   // centred, as the scoring pass saw it
-    xx = fmaf(xc, xc, xx);
+// Shape: RG = blockDim / 128 column groups of 32 rows, two waves each.  Wave (rg, c) keeps column group rg in
+// registers (bf16 pairs of its share of 32 rows) and takes chunks c and c + 2 of every staged 128-code step.  The host
+// picks RG = ceil(rows / 32 / 256) (up to VQ_MAXRG) so that ONE round of workgroups covers all rows with at most one
+// column group of imbalance, and a workgroup stages the whole codebook exactly once for its rows (LDS-DMA, double
+// buffered, 2 x 64.5 KiB for D = 128: one workgroup per CU, 2 RG waves on its four SIMDs).
+template <int D>
+__global__ __launch_bounds__(128 * VQ_MAXRG) void vq_search_kernel(const float* __restrict__ x, const float* __restrict__ cb,
+                                                        const float* __restrict__ row_mask, const float* __restrict__ mu,
+                                                        const float* __restrict__ nkhalf, unsigned* __restrict__ kmax2_bits,
+                                                        const __bf16* __restrict__ kh, const __bf16* __restrict__ kl,
+                                                        long long N, int Kpad, long long* __restrict__ idx,
+                                                        float* __restrict__ min_dist, float* __restrict__ x_d,
+                                                        int* __restrict__ q_rows, float* __restrict__ q_thr) {
+  constexpr int SUP = VQ_SSUP;
+  using G = VqGeom<D, SUP>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nw = blockDim.x >> 6, tile = 16 * nw;           // waves, rows per workgroup
+  float* m_best = reinterpret_cast<float*>(smem + 2 * G::BUF_BYTES);
+  float* m_second = m_best + tile;
+  int* m_idx = reinterpret_cast<int*>(m_second + tile);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int rg = wave >> 1, c = wave & 1;
+  const long long row0 = (long long)blockIdx.x * tile;
+
+  char* buf0 = smem;
+  char* buf1 = smem + G::BUF_BYTES;
+  VQ_STAMP(0);
+  vq_stage<D, SUP>(kh, kl, nkhalf, 0, buf0, nw, wave, lane);
+  vq_stage<D, SUP>(kh, kl, nkhalf, 1, buf1, nw, wave, lane);
+  vq_bf16x8 xh[1][G::NS], xl[1][G::NS];
+  float xx;
+  {
+    const long long row = min(row0 + 32 * rg + j, N - 1);   // rows past the end repeat the last row and are never written
+    xx = vq_load_row<D>(x, mu, row, h, xh[0], xl[0]);
+    xx += __shfl_xor(xx, 32, 64);
   }
-  xx = wave_sum(xx);
-  float best = -INFINITY, second = -INFINITY;
-  int bidx = 0;
-  for (int s = 0; s < S; ++s) {  // slice order == code order; strict '>' keeps the lowest index
-    size_t o = (size_t)row * S + s;
-    float b = p_best[o], se = p_second[o];
-    if (b > best) {
-      second = fmaxf(best, se); best = b; bidx = p_idx[o];
-    } else {
-      second = fmaxf(second, b);
+  vq_stage_wait();
+  __syncthreads();
+  VQ_STAMP(1);
+
+  float best[1] = {-INFINITY}, second[1] = {-INFINITY};
+  int bidx[1] = {0x7fffffff};
+  const int nsc = Kpad / SUP;                               // even (the prep pads to 256 codes)
+  f32x16 acc[1];
+  // The running best / runner-up costs VALU issue slots that the matrix pipe cannot hide (measured: it adds to the MFMA
+  // time), so it is cut to 3 instructions per score: the score's position r in the chunk is written into its 4 low
+  // mantissa bits (error <= 2^-19 |score|, accounted for in vq_filter_err), after which max / med3 on the tagged floats
+  // carry the position along; which chunk holds the best is noted once per chunk.
+  int bchunk = 0;
+  float pinf = INFINITY;
+  asm volatile("" : "+v"(pinf));
+  auto score_step = [&](const char* buf, int sc) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int chunk = c + 2 * q;
+      vq_chunk_scores<D, SUP, 1>(buf, chunk, j, h, xh, xl, acc);
+      if (!(VQ_ABL & 4)) {
+        const float before = best[0];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {            // v_and_or_b32, v_med3_f32, v_med3_f32 (plain builtins: the compiler
+          const float t = __int_as_float((__float_as_int(acc[0][r]) & ~15) | r);   // pads the MFMA -> VALU hazards itself)
+          second[0] = __builtin_amdgcn_fmed3f(best[0], second[0], t);
+          best[0] = __builtin_amdgcn_fmed3f(best[0], t, pinf);                     // = max; pinf is opaque, so it stays one med3
+        }
+        bchunk = best[0] != before ? sc * (SUP / VQ_CHUNK) + chunk : bchunk;
+      } else {
+        best[0] += acc[0][0] + acc[0][5] + acc[0][10] + acc[0][15];      // keeps the MFMA chain alive
+      }
+    }
+  };
+  for (int sc = 0; sc < nsc; sc += 2) {
+    score_step(buf0, sc);
+    vq_stage_wait();                                        // step sc + 1 (issued one scoring phase ago) has landed in buf1
+    __syncthreads();                                        // buf0 released
+    if (sc + 2 < nsc) vq_stage<D, SUP>(kh, kl, nkhalf, sc + 2, buf0, nw, wave, lane);
+    score_step(buf1, sc + 1);
+    vq_stage_wait();
+    __syncthreads();                                        // buf1 released, step sc + 2 landed in buf0
+    if (sc + 3 < nsc) vq_stage<D, SUP>(kh, kl, nkhalf, sc + 3, buf1, nw, wave, lane);   // lands while step sc + 2 is scored
+  }
+  VQ_STAMP(2);
+  {  // decode the winner: chunk, position tag, lane half
+    const int r = __float_as_int(best[0]) & 15;
+    bidx[0] = bchunk * VQ_CHUNK + 8 * (r >> 2) + 4 * h + (r & 3);
+  }
+  // merge the two lane halves of a row (same row, disjoint codes), then the two chunk waves of the column group
+  {
+    const float ob = __shfl_xor(best[0], 32, 64), os = __shfl_xor(second[0], 32, 64);
+    const int oi = __shfl_xor(bidx[0], 32, 64);
+    vq_merge(best[0], second[0], bidx[0], ob, os, oi);
+  }
+  float b = best[0], s2 = second[0];
+  int bi = bidx[0];
+  if (c == 1 && h == 0) { m_best[32 * rg + j] = b; m_second[32 * rg + j] = s2; m_idx[32 * rg + j] = bi; }
+  __syncthreads();
+  if (c == 0 && h == 0) {
+    const int r = 32 * rg + j;
+    vq_merge(b, s2, bi, m_best[r], m_second[r], m_idx[r]);
+    const long long row = row0 + r;
+    const float err = vq_filter_err(xx, __uint_as_float(kmax2_bits[0]), D);
+    const bool ambiguous = !((b - s2) > 2.0f * err);        // also catches NaN / inf
+    int res = bi;
+    if (row < N && ambiguous) {
+      const int q = atomicAdd(reinterpret_cast<int*>(kmax2_bits + 32), 1);
+      q_rows[q] = (int)row;
+      q_thr[q] = b - 2.0f * err;
+      res = -1;
+    }
+    m_idx[r] = res;
+  }
+  __syncthreads();
+  VQ_STAMP(3);
+  // finish the unambiguous rows: idx, min_dist = |x - k_idx|^2 (fp32 direct form), x_d = k_idx * mask.
+  // LPR lanes per row, RPI rows per wave-instruction, 16 rows per wave; loads of a batch are issued together.
+  constexpr int RPW = 16, LPR = D / 4, RPI = 64 / LPR, NIT = RPW / RPI, BATCH = NIT < 4 ? NIT : 4;
+  const int c4 = lane % LPR;
+#pragma unroll 1
+  for (int it0 = 0; it0 < ((VQ_ABL & 8) ? 0 : NIT); it0 += BATCH) {
+    f32x4 xv[BATCH], kv[BATCH];
+    int code[BATCH];
+    long long rows[BATCH];
+#pragma unroll
+    for (int q = 0; q < BATCH; ++q) {
+      const int r = RPW * wave + (it0 + q) * RPI + lane / LPR;
+      rows[q] = row0 + r;
+      code[q] = m_idx[r];
+      xv[q] = *reinterpret_cast<const f32x4*>(x + min(rows[q], N - 1) * D + 4 * c4);
+      kv[q] = *reinterpret_cast<const f32x4*>(cb + (size_t)max(code[q], 0) * D + 4 * c4);
+    }
+#pragma unroll
+    for (int q = 0; q < BATCH; ++q) {
+      const f32x4 df = xv[q] - kv[q];
+      float ds = fmaf(df.w, df.w, fmaf(df.z, df.z, fmaf(df.y, df.y, df.x * df.x)));
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) ds += __shfl_xor(ds, o, 64);
+      if (rows[q] < N && code[q] >= 0) {
+        if (x_d) {
+          const float m = row_mask ? row_mask[rows[q]] : 1.f;
+          *reinterpret_cast<f32x4*>(x_d + rows[q] * D + 4 * c4) = kv[q] * m;
+        }
+        if (c4 == 0) { idx[rows[q]] = code[q]; min_dist[rows[q]] = ds; }
+      }
     }
   }
-  // Error of the filter score against the exact acc = x~.k~ - |k~|^2/2 on the centred operands
-  // (norms below are the centred ones, Cauchy-Schwarz turns sums of products into norm products):
-  //   bf16-pair split, three of the four partial products kept:  <= 3.01 * 2^-18 |x~| |k~|
-  //   fp32 accumulation of 3D exact products + the initial term:  <= 1.05 (3D+2) 2^-24 (|x~||k~| + |k~|^2/2)
-  //   fp32 rounding of khalf and of the centring x - mu, k - mu:  <= 2^-24 ((D+2)|k~|^2/2 + (|x~| + |k~|)^2)
-  // with |k~| <= |k~|max; a factor 1.25 of slack covers the MFMA's internal summation order.
-  const float kmax2 = __uint_as_float(*kmax2_bits);
-  const float xk = sqrtf(xx * kmax2);
-  const float u24 = 5.9604645e-8f;
-  const float err = 1.25f * (3.01f * 64.f * u24 * xk + 1.05f * (float)(3 * D + 2) * u24 * (xk + 0.5f * kmax2) +
-                             u24 * (0.5f * (float)(D + 2) * kmax2 + xx + 2.f * xk + kmax2));
-  const bool ambiguous = !((best - second) > 2.0f * err);  // also catches NaN / inf
-  if (ambiguous) {
-    if (lane == 0) q_rows[atomicAdd(q_count, 1)] = (int)row;
-    return;
-  }
-  const float m = row_mask ? row_mask[row] : 1.f;
-  const float* kr = cb + (size_t)bidx * D;
-  float dsum = 0.f;
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    int i = lane + 64 * u;
-    if (i < D) {
-      float kv = kr[i];
-      float df = xv[u] - kv;
-      dsum = fmaf(df, df, dsum);
-      if (x_d) x_d[row * D + i] = kv * m;
-    }
-  }
-  dsum = wave_sum(dsum);
-  if (lane == 0) {
-    idx[row] = bidx;
-    min_dist[row] = dsum;
-  }
+  VQ_STAMP(4);
 }
 
-// ---------------------------------------------------------------- rescore ---
-// Exact fp64 re-scoring of queued rows over ALL codes: d_j = sum_i (x_i - k_ji)^2 accumulated in index
-// order without fma contraction (== the numpy float64 loop of the oracle).  A workgroup takes up to RB queued
-// rows at a time; thread t owns code (block*256 + t) and scores it against all of them, so one pass of the
-// codebook through LDS ([256 codes][32 dims], pitch 33 floats: coalesced 16-byte global reads, conflict-free
-// per-code walks) serves RB rows -- with one row per workgroup the 512 KiB codebook was re-staged per row,
-// which made this kernel the largest part of smt_vq_forward on an untrained encoder (many near-tie rows).
-constexpr int VQ_RB = 8;
-template <int NR>
-__device__ __forceinline__ void vq_rescore_accum(const float* kr, const double (*xs)[256], int d0, int dn, double* acc) {
-  for (int i = 0; i < dn; ++i) {
-    const double kv = (double)kr[i];
-#pragma unroll
-    for (int rr = 0; rr < NR; ++rr) {
-      const double df = __dsub_rn(xs[rr][d0 + i], kv);
-      acc[rr] = __dadd_rn(acc[rr], __dmul_rn(df, df));
-    }
-  }
-}
-__global__ __launch_bounds__(256) void vq_rescore_kernel(const float* __restrict__ x, const float* __restrict__ cb,
-                                                         const float* __restrict__ row_mask, long long N, int K, int D,
-                                                         const int* __restrict__ q_count, const int* __restrict__ q_rows,
-                                                         long long* __restrict__ idx, float* __restrict__ min_dist,
-                                                         float* __restrict__ x_d) {
-  constexpr int HB = 32, PITCH = 33, RB = VQ_RB;     // 33.8 KiB tile + 16 KiB of rows: three workgroups per CU
-  __shared__ double xs[RB][256];
-  __shared__ float tile[256 * PITCH];
-  __shared__ double red_d[256];
-  __shared__ int red_i[256];
-  const int n_q = *q_count;
-  const int halves = (D + HB - 1) / HB;
-  // rows per workgroup and pass: as few as keeps every workgroup busy, at most RB
-  const int rpw = max(1, min(RB, (n_q + (int)gridDim.x - 1) / (int)gridDim.x));
-  for (int q0 = blockIdx.x * rpw; q0 < n_q; q0 += gridDim.x * rpw) {
-    const int nr = min(rpw, n_q - q0);
+// ---------------------------------------------------------------- candidates
+// Queued rows, 32 at a time, the code range cut into `splits` pieces (one workgroup per (row group, piece)): with filter
+// scores f_j (|f_j - s_j| <= err against the exact scores s_j) and the first pass's maximum fmax, the exact winner j*
+// satisfies f_j* >= s_j* - err >= s_jmax - err >= fmax - 2 err for ANY filter values within err of the truth -- so every
+// code whose score here reaches thr = fmax - 2 err is recorded (up to VQ_CAPS per row and piece; the count is recorded
+// in full so that vq_exact sees an overflow).
+template <int D>
+__global__ __launch_bounds__(128) void vq_candidates_kernel(const float* __restrict__ x, const float* __restrict__ mu,
+                                                            const float* __restrict__ nkhalf, const unsigned* __restrict__ kmax2_bits,
+                                                            const __bf16* __restrict__ kh, const __bf16* __restrict__ kl,
+                                                            int Kpad, int splits, const int* __restrict__ q_rows,
+                                                            const float* __restrict__ q_thr, int* __restrict__ c_count,
+                                                            int* __restrict__ c_codes) {
+  constexpr int SUP = VQ_CSUP;
+  using G = VqGeom<D, SUP>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int l_cnt[32];
+  __shared__ int l_code[32][VQ_CAPS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int n_q = (int)kmax2_bits[32];
+  const int nsc = Kpad / SUP, per = nsc / splits;      // staged steps per piece
+  const int ntask = ((n_q + 31) / 32) * splits;
+  for (int task = blockIdx.x; task < ntask; task += gridDim.x) {
+    const int rg = task / splits, sp = task % splits;
+    __syncthreads();                                        // the previous task's lists are no longer read
+    if (threadIdx.x < 32) l_cnt[threadIdx.x] = 0;
+    const int qi = min(rg * 32 + j, n_q - 1);
+    const float thr = rg * 32 + j < n_q ? q_thr[qi] : INFINITY;
+    vq_stage<D, SUP>(kh, kl, nkhalf, sp * per, smem, 2, wave, lane);
+    vq_bf16x8 xh[1][G::NS], xl[1][G::NS];
+    (void)vq_load_row<D>(x, mu, (long long)q_rows[qi], h, xh[0], xl[0]);
+    vq_stage_wait();
     __syncthreads();
-    for (int f = threadIdx.x; f < nr * D; f += 256) {
-      const int rr = f / D, i = f - rr * D;
-      xs[rr][i] = (double)x[(long long)q_rows[q0 + rr] * D + i];
-    }
-    double bd[RB];
-    int bi[RB];
+    for (int i = 0; i < per; ++i) {
+      const int buf = i & 1, sc = sp * per + i;
+      if (i + 1 < per) vq_stage<D, SUP>(kh, kl, nkhalf, sc + 1, smem + (buf ^ 1) * G::BUF_BYTES, 2, wave, lane);
+      f32x16 acc[1];
+      vq_chunk_scores<D, SUP, 1>(smem + buf * G::BUF_BYTES, wave, j, h, xh, xl, acc);
+      const int cbase = sc * SUP + wave * VQ_CHUNK + 4 * h;
 #pragma unroll
-    for (int rr = 0; rr < RB; ++rr) { bd[rr] = INFINITY; bi[rr] = 0x7fffffff; }
-    for (int c0 = 0; c0 < K; c0 += 256) {
-      double acc[RB];
-#pragma unroll
-      for (int rr = 0; rr < RB; ++rr) acc[rr] = 0.0;
-      for (int hf = 0; hf < halves; ++hf) {
-        const int d0 = hf * HB, dn = min(HB, D - d0);          // dims [d0, d0 + dn), dn % 4 == 0
-        __syncthreads();
-        const int v_per_code = dn / 4;
-        for (int f = threadIdx.x; f < 256 * v_per_code; f += 256) {
-          const int code = f / v_per_code, c4 = f % v_per_code;
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (c0 + code < K) v = *reinterpret_cast<const f32x4*>(cb + (size_t)(c0 + code) * D + d0 + 4 * c4);
-          float* dst = &tile[code * PITCH + 4 * c4];
-          dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-        }
-        __syncthreads();
-        const float* kr = &tile[threadIdx.x * PITCH];
-        switch (nr) {                                            // workgroup-uniform: straight-line code per row count
-          case 1: vq_rescore_accum<1>(kr, xs, d0, dn, acc); break;
-          case 2: vq_rescore_accum<2>(kr, xs, d0, dn, acc); break;
-          case 3: vq_rescore_accum<3>(kr, xs, d0, dn, acc); break;
-          case 4: vq_rescore_accum<4>(kr, xs, d0, dn, acc); break;
-          case 5: vq_rescore_accum<5>(kr, xs, d0, dn, acc); break;
-          case 6: vq_rescore_accum<6>(kr, xs, d0, dn, acc); break;
-          case 7: vq_rescore_accum<7>(kr, xs, d0, dn, acc); break;
-          default: vq_rescore_accum<8>(kr, xs, d0, dn, acc); break;
+      for (int r = 0; r < 16; ++r) {
+        if (acc[0][r] >= thr) {                             // padding codes score -inf, NaN compares false
+          const int pos = atomicAdd(&l_cnt[j], 1);
+          if (pos < VQ_CAPS) l_code[j][pos] = cbase + 8 * (r >> 2) + (r & 3);
         }
       }
-      const int code = c0 + threadIdx.x;
-#pragma unroll
-      for (int rr = 0; rr < RB; ++rr)
-        if (code < K && acc[rr] < bd[rr]) { bd[rr] = acc[rr]; bi[rr] = code; }   // increasing code order: lowest index on ties
-    }
-#pragma unroll
-    for (int rr = 0; rr < RB; ++rr) {
-      if (rr >= nr) break;                                       // workgroup-uniform
+      vq_stage_wait();
       __syncthreads();
-      red_d[threadIdx.x] = bd[rr];
-      red_i[threadIdx.x] = bi[rr];
-      __syncthreads();
-      for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) {
-          double od = red_d[threadIdx.x + o];
-          int oi = red_i[threadIdx.x + o];
-          if (od < red_d[threadIdx.x] || (od == red_d[threadIdx.x] && oi < red_i[threadIdx.x])) {
-            red_d[threadIdx.x] = od; red_i[threadIdx.x] = oi;
-          }
-        }
-        __syncthreads();
+    }
+    if (threadIdx.x < 32 && rg * 32 + (int)threadIdx.x < n_q) {
+      const size_t slot = (size_t)(rg * 32 + threadIdx.x) * splits + sp;
+      c_count[slot] = l_cnt[threadIdx.x];
+#pragma unroll
+      for (int c = 0; c < VQ_CAPS; ++c) c_codes[slot * VQ_CAPS + c] = l_code[threadIdx.x][c];
+    }
+  }
+}
+
+// ---------------------------------------------------------------- exact -----
+// d_j = sum_i (x_i - k_ji)^2 in fp64, index order, no fma contraction (the numpy float64 loop of the oracle)
+__device__ __forceinline__ double vq_exact_dist(const float* __restrict__ xr, const float* __restrict__ kr, int D) {
+  double d = 0.0;
+#pragma unroll 4
+  for (int i = 0; i < D; i += 4) {
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + i), kv = *reinterpret_cast<const f32x4*>(kr + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const double df = __dsub_rn((double)xv[e], (double)kv[e]);
+      d = __dadd_rn(d, __dmul_rn(df, df));
+    }
+  }
+  return d;
+}
+// Half a wave per queued row, one lane per candidate slot (splits * VQ_CAPS <= 32); lowest index among equal distances.
+// A row with no candidate or an overflowing piece (NaN input, degenerate codebook) scans all K codes the same way.
+__global__ __launch_bounds__(256) void vq_exact_kernel(const float* __restrict__ x, const float* __restrict__ cb,
+                                                       const float* __restrict__ row_mask, const unsigned* __restrict__ kmax2_bits,
+                                                       int K, int D, int splits, const int* __restrict__ q_rows,
+                                                       const int* __restrict__ c_count, const int* __restrict__ c_codes,
+                                                       long long* __restrict__ idx, float* __restrict__ min_dist,
+                                                       float* __restrict__ x_d) {
+  const int n_q = (int)kmax2_bits[32];
+  const int lane = threadIdx.x & 63, half = lane >> 5, l = lane & 31;
+  const int hw0 = (((int)blockIdx.x * 256 + (int)threadIdx.x) >> 6) * 2, nhw = (int)gridDim.x * 8;
+  for (int q0 = hw0; q0 < n_q; q0 += nhw) {                  // wave-uniform trip count; the second half may idle
+    const int qi = q0 + half;
+    const bool rvalid = qi < n_q;
+    const long long row = rvalid ? q_rows[qi] : 0;
+    const float* xr = x + row * D;
+    const int sp = l / VQ_CAPS, c = l % VQ_CAPS;
+    int n = 0;
+    if (rvalid && sp < splits) n = c_count[(size_t)qi * splits + sp];
+    // any piece over capacity, or no candidate at all, anywhere in this half-wave's row?
+    const unsigned long long over = __ballot(n > VQ_CAPS), some = __ballot(n > 0);
+    const unsigned long long hmask = half ? 0xffffffff00000000ull : 0x00000000ffffffffull;
+    const bool full = rvalid && ((over & hmask) != 0 || (some & hmask) == 0);
+    double d = INFINITY;
+    int code = 0x7fffffff;
+    if (rvalid && !full && c < n) {
+      code = c_codes[((size_t)qi * splits + sp) * VQ_CAPS + c];
+      d = vq_exact_dist(xr, cb + (size_t)code * D, D);
+    }
+    if (full) {
+      for (int c0 = l; c0 < K; c0 += 32) {                   // increasing code order per lane: strict '<' keeps the lowest
+        const double dc = vq_exact_dist(xr, cb + (size_t)c0 * D, D);
+        if (dc < d) { d = dc; code = c0; }
       }
-      const long long row = q_rows[q0 + rr];
-      const int wi = red_i[0];
-      const float m = row_mask ? row_mask[row] : 1.f;
-      if (x_d && threadIdx.x < D) x_d[row * D + threadIdx.x] = cb[(size_t)wi * D + threadIdx.x] * m;
-      if (threadIdx.x == 0) {
-        idx[row] = wi;
-        min_dist[row] = (float)red_d[0];   // the exact distance, rounded once
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      const double od = __shfl_xor(d, o, 64);
+      const int oc = __shfl_xor(code, o, 64);
+      if (od < d || (od == d && oc < code)) { d = od; code = oc; }
+    }
+    if (rvalid && code != 0x7fffffff) {
+      if (x_d) {
+        const float m = row_mask ? row_mask[row] : 1.f;
+        for (int i = l; i < D; i += 32) x_d[row * D + i] = cb[(size_t)code * D + i] * m;
       }
+      if (l == 0) { idx[row] = code; min_dist[row] = (float)d; }   // the exact distance, rounded once
+    } else if (rvalid && l == 0) {                                 // NaN row: keep the outputs defined
+      idx[row] = 0; min_dist[row] = __builtin_nanf("");
     }
   }
 }
 
 // ---------------------------------------------------------------- reduce ----
-// Single workgroup, fixed order: sums[0] = sum_all min_dist, sums[1] = sum_masked,
-// sums[2] = sum mask, sums[3] = queued rows.
+// Single workgroup, fixed order: sums[0] = sum_all min_dist, sums[1] = sum_masked, sums[2] = sum mask,
+// sums[3] = rows that were re-scored exactly.  Resets the queue counter for the next forward.
 __global__ __launch_bounds__(1024) void vq_reduce_kernel(const float* __restrict__ min_dist,
                                                          const float* __restrict__ row_mask, long long N,
-                                                         const int* __restrict__ q_count, float* __restrict__ sums) {
+                                                         unsigned* __restrict__ kmax2_bits, float* __restrict__ sums) {
   __shared__ double sh[3][16];
   double a = 0.0, b = 0.0, c = 0.0;
-  for (long long r = threadIdx.x; r < N; r += 1024) {
-    float d = min_dist[r];
-    float m = row_mask ? row_mask[r] : 1.f;
-    a += d; b += (m != 0.f) ? d : 0.f; c += m;
+  constexpr int U = 10;                                     // 16-byte loads in flight per thread: 40,960 rows per pass
+  for (long long r0 = 4ll * threadIdx.x; r0 < N; r0 += 4096ll * U) {
+    f32x4 d[U], m[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long r = r0 + 4096ll * u;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f}, one = {1.f, 1.f, 1.f, 1.f};
+      if (r + 3 < N) {
+        d[u] = *reinterpret_cast<const f32x4*>(min_dist + r);
+        m[u] = row_mask ? *reinterpret_cast<const f32x4*>(row_mask + r) : one;
+      } else {
+        d[u] = z; m[u] = z;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (r + e < N) { d[u][e] = min_dist[r + e]; m[u][e] = row_mask ? row_mask[r + e] : 1.f; }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a += d[u][e]; b += (m[u][e] != 0.f) ? d[u][e] : 0.f; c += m[u][e]; }
   }
   a = wave_sum_d(a); b = wave_sum_d(b); c = wave_sum_d(c);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -396,13 +625,13 @@ __global__ __launch_bounds__(1024) void vq_reduce_kernel(const float* __restrict
   if (threadIdx.x == 0) {
     double ta = 0, tb = 0, tc = 0;
     for (int w = 0; w < 16; ++w) { ta += sh[0][w]; tb += sh[1][w]; tc += sh[2][w]; }
-    sums[0] = (float)ta; sums[1] = (float)tb; sums[2] = (float)tc; sums[3] = (float)(*q_count);
+    sums[0] = (float)ta; sums[1] = (float)tb; sums[2] = (float)tc; sums[3] = (float)kmax2_bits[32];
+    kmax2_bits[32] = 0u;
   }
 }
 
 // ---------------------------------------------------------------- backward --
-__global__ __launch_bounds__(256) void vq_backward_kernel(const float* __restrict__ x, const float* __restrict__ cb,
-                                                          const long long* __restrict__ idx,
+__global__ __launch_bounds__(256) void vq_backward_kernel(const float* __restrict__ x, const float* __restrict__ x_d,
                                                           const float* __restrict__ row_mask, const float* __restrict__ dy,
                                                           const float* __restrict__ g_commit, const float* __restrict__ sums,
                                                           long long N, int D, float* __restrict__ dx) {
@@ -411,7 +640,6 @@ __global__ __launch_bounds__(256) void vq_backward_kernel(const float* __restric
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total4;
        e += (long long)gridDim.x * blockDim.x) {
     const long long row = (e * 4) / D;
-    const int col = (int)((e * 4) % D);
     const float m = row_mask ? row_mask[row] : 1.f;
     f32x4 xv = *reinterpret_cast<const f32x4*>(x + e * 4);
     f32x4 out = {0.f, 0.f, 0.f, 0.f};
@@ -420,7 +648,7 @@ __global__ __launch_bounds__(256) void vq_backward_kernel(const float* __restric
       out = g * m;
     }
     if (g_commit && m != 0.f) {
-      f32x4 kv = *reinterpret_cast<const f32x4*>(cb + (size_t)idx[row] * D + col);
+      f32x4 kv = *reinterpret_cast<const f32x4*>(x_d + e * 4);      // = k[idx[row]] on unmasked rows (0/1 masks)
       out += (xv - kv) * gc;
     }
     *reinterpret_cast<f32x4*>(dx + e * 4) = out;
@@ -446,151 +674,168 @@ __global__ __launch_bounds__(256) void vq_ema_accumulate_kernel(const float* __r
   }
 }
 
-// Single workgroup (K*D is ~1e5): EMA mix, revival, metrics -- all reductions in fixed order.
-__global__ __launch_bounds__(1024) void vq_ema_apply_kernel(float* __restrict__ cb, float* __restrict__ k_sum,
-                                                            float* __restrict__ k_elem, const float* __restrict__ stats,
-                                                            const float* __restrict__ k_rand, float mu, float threshold,
-                                                            int K, int D, float* __restrict__ metrics) {
-  __shared__ double sh[16];
-  __shared__ double bc;
-  auto block_sum = [&](double v) -> double {
-    v = wave_sum_d(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double t = 0;
-      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
-      bc = t;
-    }
-    __syncthreads();
-    return bc;
-  };
+// EMA mix + revival for VQ_PART codes per workgroup (bottleneck.py:78-84); leaves the partial column sums of the NEW
+// codebook and the partial sums of (k_new - k_old)^2 for vq_mu_kernel, which finishes the metrics in fixed order.
+__global__ __launch_bounds__(256) void vq_ema_apply_kernel(float* __restrict__ cb, float* __restrict__ k_sum,
+                                                           float* __restrict__ k_elem, const float* __restrict__ stats,
+                                                           const float* __restrict__ k_rand, float mu, float threshold,
+                                                           int K, int D, float* __restrict__ part, double* __restrict__ dkpart) {
+  __shared__ float slab[VQ_PART * 128];
+  __shared__ double red[4];
+  const int j0 = blockIdx.x * VQ_PART;
+  const int n = min(VQ_PART, K - j0) * D;
   const float* cnt = stats + (size_t)K * D;
-  double tot = 0.0;
-  for (int j = threadIdx.x; j < K; j += blockDim.x) tot += cnt[j];
-  const float total = (float)block_sum(tot);
-
-  double ent = 0.0, used = 0.0, usage_n = 0.0;
-  for (int j = threadIdx.x; j < K; j += blockDim.x) {
-    float c = cnt[j];
-    float prob = c / total;
-    ent += -(double)(prob * logf(fmaxf(prob, 1e-5f)));
-    used += (c >= threshold) ? 1.0 : 0.0;
-    float ne = mu * k_elem[j] + (1.f - mu) * c;
-    usage_n += (ne >= threshold) ? 1.0 : 0.0;
-  }
-  ent = block_sum(ent);
-  used = block_sum(used);
-  usage_n = block_sum(usage_n);
-
   double dk2 = 0.0;
-  for (int e = threadIdx.x; e < K * D; e += blockDim.x) {
-    int j = e / D;
-    float ne = mu * k_elem[j] + (1.f - mu) * cnt[j];   // k_elem is rewritten only after this loop
-    float ns = mu * k_sum[e] + (1.f - mu) * stats[e];
-    float usage = (ne >= threshold) ? 1.f : 0.f;
-    float nk = usage * (ns / ne) + (1.f - usage) * k_rand[e];
-    float d = nk - cb[e];
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const int j = j0 + e / D;
+    const size_t ge = (size_t)j0 * D + e;
+    const float ne = mu * k_elem[j] + (1.f - mu) * cnt[j];   // k_elem is rewritten only after the barrier below
+    const float ns = mu * k_sum[ge] + (1.f - mu) * stats[ge];
+    const float usage = (ne >= threshold) ? 1.f : 0.f;
+    const float nk = usage * (ns / ne) + (1.f - usage) * k_rand[ge];
+    const float d = nk - cb[ge];
     dk2 += (double)d * d;
-    k_sum[e] = ns;
-    cb[e] = nk;
+    k_sum[ge] = ns;
+    cb[ge] = nk;
+    slab[e] = nk;
   }
-  dk2 = block_sum(dk2);
+  dk2 = wave_sum_d(dk2);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dk2;
   __syncthreads();
-  for (int j = threadIdx.x; j < K; j += blockDim.x) k_elem[j] = mu * k_elem[j] + (1.f - mu) * cnt[j];
-  if (threadIdx.x == 0) {
-    metrics[0] = (float)ent;
-    metrics[1] = (float)used;
-    metrics[2] = (float)usage_n;
-    metrics[3] = (float)(sqrt(dk2) / sqrt((double)K * D));
+  if ((int)threadIdx.x < min(VQ_PART, K - j0)) {
+    const int j = j0 + threadIdx.x;
+    k_elem[j] = mu * k_elem[j] + (1.f - mu) * cnt[j];
+  }
+  if (threadIdx.x == 0) dkpart[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+  if ((int)threadIdx.x < D) {
+    float t = 0.f;
+    for (int q = 0; q < min(VQ_PART, K - j0); ++q) t += slab[q * D + threadIdx.x];
+    part[(size_t)blockIdx.x * D + threadIdx.x] = t;
   }
 }
 
-struct VqWorkspace {
-  float* khalf; unsigned* kmax2; int* q_count; float* p_best; int* p_idx; float* p_second; int* q_rows;
-  float* mu; __bf16* kh; __bf16* kl;
-};
+struct VqWorkspace { int* q_rows; float* q_thr; int* c_count; int* c_codes; void* prep; };
 
-static size_t vq_layout(long long N, int K, int D, int S, void* base, VqWorkspace* w) {
+static size_t vq_layout(long long N, int K, int D, void* base, VqWorkspace* w) {
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return (char*)base + o; };
   char* p;
-  p = take((size_t)K * 4); if (w) w->khalf = (float*)p;
-  p = take(256);           if (w) { w->kmax2 = (unsigned*)p; w->q_count = (int*)(p + 128); }
-  p = take((size_t)N * S * 4); if (w) w->p_best = (float*)p;
-  p = take((size_t)N * S * 4); if (w) w->p_idx = (int*)p;
-  p = take((size_t)N * S * 4); if (w) w->p_second = (float*)p;
-  p = take((size_t)N * 4);     if (w) w->q_rows = (int*)p;
-  p = take((size_t)D * 4);     if (w) w->mu = (float*)p;
-  p = take((size_t)K * D * 2); if (w) w->kh = (__bf16*)p;
-  p = take((size_t)K * D * 2); if (w) w->kl = (__bf16*)p;
+  p = take((size_t)N * 4); if (w) w->q_rows = (int*)p;
+  p = take((size_t)N * 4); if (w) w->q_thr = (float*)p;
+  p = take((size_t)N * VQ_SPLITS * 4);           if (w) w->c_count = (int*)p;
+  p = take((size_t)N * VQ_SPLITS * VQ_CAPS * 4); if (w) w->c_codes = (int*)p;
+  p = take(vq_prep_layout(K, D, nullptr, nullptr)); if (w) w->prep = p;   // used when the caller passes no prep buffer
   return off;
+}
+
+// column sums -> mu (-> metrics) -> centred split: the three launches behind smt_vq_prepare and smt_vq_ema_apply
+static int vq_finish_prepare(const float* cb, int K, int D, const VqPrep& pr, const float* cnt, const float* k_elem,
+                             float threshold, float* metrics, hipStream_t stream) {
+  vq_mu_kernel<<<1, 1024, 0, stream>>>(pr.part, pr.nparts, K, D, pr.mu, pr.kmax2, cnt, k_elem, pr.dkpart, threshold, metrics);
+  SMT_CHECK_LAUNCH("vq_mu");
+  vq_split_kernel<<<(pr.kpad + 15) / 16, 1024, 0, stream>>>(cb, pr.mu, K, pr.kpad, D, pr.kh, pr.kl, pr.nkhalf, pr.kmax2);
+  SMT_CHECK_LAUNCH("vq_split");
+  return 0;
+}
+
+template <int D>
+static int vq_launch_search(const float* x, const float* cb, const float* row_mask, const VqPrep& pr, long long N, int K,
+                            long long* idx, float* min_dist, float* x_d, const VqWorkspace& w, hipStream_t stream) {
+  using GS = VqGeom<D, VQ_SSUP>;
+  using GC = VqGeom<D, VQ_CSUP>;
+  const long long groups = (N + 31) / 32;
+  // column groups per workgroup: one round of at most 256 workgroups when that fits (<= VQ_MAXRG groups each)
+  const int rgs = (int)std::min<long long>(VQ_MAXRG, (groups + 255) / 256);
+  const size_t lds = 2 * GS::BUF_BYTES + 3 * 32 * rgs * 4;
+  (void)hipFuncSetAttribute((const void*)vq_search_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * GS::BUF_BYTES + 3 * 32 * VQ_MAXRG * 4));
+  (void)hipFuncSetAttribute((const void*)vq_candidates_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GC::BUF_BYTES);
+  vq_search_kernel<D><<<(unsigned)((groups + rgs - 1) / rgs), 128 * rgs, lds, stream>>>(
+      x, cb, row_mask, pr.mu, pr.nkhalf, pr.kmax2, pr.kh, pr.kl, N, pr.kpad, idx, min_dist, x_d, w.q_rows, w.q_thr);
+  SMT_CHECK_LAUNCH("vq_search");
+  const int nsc = pr.kpad / VQ_CSUP;
+  int splits = VQ_SPLITS;
+  while (nsc % splits) splits >>= 1;                         // nsc is a multiple of 4
+  vq_candidates_kernel<D><<<(unsigned)std::min<long long>(512, groups * splits), 128, 2 * GC::BUF_BYTES, stream>>>(
+      x, pr.mu, pr.nkhalf, pr.kmax2, pr.kh, pr.kl, pr.kpad, splits, w.q_rows, w.q_thr, w.c_count, w.c_codes);
+  SMT_CHECK_LAUNCH("vq_candidates");
+  vq_exact_kernel<<<(unsigned)std::min<long long>(256, (N + 7) / 8), 256, 0, stream>>>(
+      x, cb, row_mask, pr.kmax2, K, D, splits, w.q_rows, w.c_count, w.c_codes, idx, min_dist, x_d);
+  SMT_CHECK_LAUNCH("vq_exact");
+  return 0;
 }
 
 }  // namespace smt
 
 using namespace smt;
 
-extern "C" size_t smt_vq_forward_workspace_bytes(int64_t n_rows, int k_bins, int dim) {
-  int S = (k_bins + VQ_SLICE - 1) / VQ_SLICE;
-  return vq_layout(n_rows, k_bins, dim, S, nullptr, nullptr);
+#if VQ_ABL & 16
+extern "C" int smt_vq_debug_dump(long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vq_dbg), sizeof(long long) * n);
+}
+#endif
+
+extern "C" size_t smt_vq_prep_bytes(int k_bins, int dim) { return vq_prep_layout(k_bins, dim, nullptr, nullptr); }
+
+extern "C" int smt_vq_prepare(const float* codebook, int k_bins, int dim, void* prep, size_t prep_bytes, smt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SMT_CHECK_ARG(dim == 32 || dim == 64 || dim == 128, "smt_vq_prepare: dim must be 32, 64 or 128 (got %d)", dim);
+  SMT_CHECK_ARG(codebook && prep && k_bins >= 1, "smt_vq_prepare: null pointer / bad size");
+  SMT_CHECK_ARG(prep_bytes >= vq_prep_layout(k_bins, dim, nullptr, nullptr), "smt_vq_prepare: prep buffer too small");
+  VqPrep pr;
+  vq_prep_layout(k_bins, dim, prep, &pr);
+  vq_colsum_kernel<<<pr.nparts, 128, 0, stream>>>(codebook, k_bins, dim, pr.part);
+  SMT_CHECK_LAUNCH("vq_colsum");
+  return vq_finish_prepare(codebook, k_bins, dim, pr, nullptr, nullptr, 0.f, nullptr, stream);
 }
 
-extern "C" int smt_vq_forward(const float* x, const float* codebook, const float* row_mask, int64_t n_rows, int k_bins,
-                              int dim, int64_t* idx, float* min_dist, float* x_d, float* sums, void* workspace,
-                              size_t workspace_bytes, smt_stream_t stream_) {
+extern "C" size_t smt_vq_forward_workspace_bytes(int64_t n_rows, int k_bins, int dim) {
+  return vq_layout(n_rows, k_bins, dim, nullptr, nullptr);
+}
+
+extern "C" int smt_vq_forward(const float* x, const float* codebook, void* prep, const float* row_mask,
+                              int64_t n_rows, int k_bins, int dim, int64_t* idx, float* min_dist, float* x_d, float* sums,
+                              void* workspace, size_t workspace_bytes, smt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SMT_CHECK_ARG(dim == 32 || dim == 64 || dim == 128, "smt_vq_forward: dim must be 32, 64 or 128 (got %d)", dim);
   SMT_CHECK_ARG(k_bins >= 1 && n_rows >= 0, "smt_vq_forward: bad sizes n_rows=%lld k_bins=%d", (long long)n_rows, k_bins);
   SMT_CHECK_ARG(n_rows < (1ll << 31), "smt_vq_forward: n_rows must be < 2^31");
   SMT_CHECK_ARG(codebook && sums && workspace, "smt_vq_forward: null pointer");
   SMT_CHECK_ARG(n_rows == 0 || (x && idx && min_dist), "smt_vq_forward: null pointer");
-  const int S = (k_bins + VQ_SLICE - 1) / VQ_SLICE;
-  SMT_CHECK_ARG(workspace_bytes >= vq_layout(n_rows, k_bins, dim, S, nullptr, nullptr), "smt_vq_forward: workspace too small");
+  SMT_CHECK_ARG(workspace_bytes >= vq_layout(n_rows, k_bins, dim, nullptr, nullptr), "smt_vq_forward: workspace too small");
   VqWorkspace w;
-  vq_layout(n_rows, k_bins, dim, S, workspace, &w);
-  (void)hipMemsetAsync(w.kmax2, 0, 256, stream);
+  vq_layout(n_rows, k_bins, dim, workspace, &w);
   if (n_rows == 0) {
     (void)hipMemsetAsync(sums, 0, 16, stream);
     return 0;
   }
-  vq_mean_kernel<<<1, 1024, 0, stream>>>(codebook, k_bins, dim, w.mu);
-  SMT_CHECK_LAUNCH("vq_mean");
-  vq_prep_kernel<<<(k_bins * 64 + 255) / 256, 256, 0, stream>>>(codebook, w.mu, k_bins, dim, w.kh, w.kl, w.khalf, w.kmax2);
-  SMT_CHECK_LAUNCH("vq_prep");
-  const long long tiles = (n_rows + VQ_ROWS_PER_WG - 1) / VQ_ROWS_PER_WG;
-  const unsigned grid = (unsigned)(tiles * S);
-  if (dim == 128)
-    vq_score_kernel<128><<<grid, 256, 0, stream>>>(x, w.kh, w.kl, w.mu, w.khalf, n_rows, k_bins, S, w.p_best, w.p_idx, w.p_second);
-  else if (dim == 64)
-    vq_score_kernel<64><<<grid, 256, 0, stream>>>(x, w.kh, w.kl, w.mu, w.khalf, n_rows, k_bins, S, w.p_best, w.p_idx, w.p_second);
-  else
-    vq_score_kernel<32><<<grid, 256, 0, stream>>>(x, w.kh, w.kl, w.mu, w.khalf, n_rows, k_bins, S, w.p_best, w.p_idx, w.p_second);
-  SMT_CHECK_LAUNCH("vq_score");
-  vq_finalize_kernel<<<(unsigned)((n_rows * 64 + 255) / 256), 256, 0, stream>>>(
-      x, codebook, w.mu, row_mask, w.kmax2, w.p_best, w.p_idx, w.p_second, n_rows, dim, S, (long long*)idx, min_dist, x_d,
-      w.q_count, w.q_rows);
-  SMT_CHECK_LAUNCH("vq_finalize");
-  vq_rescore_kernel<<<512, 256, 0, stream>>>(x, codebook, row_mask, n_rows, k_bins, dim, w.q_count, w.q_rows,
-                                             (long long*)idx, min_dist, x_d);
-  SMT_CHECK_LAUNCH("vq_rescore");
-  vq_reduce_kernel<<<1, 1024, 0, stream>>>(min_dist, row_mask, n_rows, w.q_count, sums);
+  VqPrep pr;
+  if (prep) {
+    vq_prep_layout(k_bins, dim, prep, &pr);
+  } else {                                   // no cached split of this codebook: build one in the workspace
+    int rc = smt_vq_prepare(codebook, k_bins, dim, w.prep, vq_prep_layout(k_bins, dim, nullptr, nullptr), stream_);
+    if (rc) return rc;
+    vq_prep_layout(k_bins, dim, w.prep, &pr);
+  }
+  int rc;
+  if (dim == 128) rc = vq_launch_search<128>(x, codebook, row_mask, pr, n_rows, k_bins, (long long*)idx, min_dist, x_d, w, stream);
+  else if (dim == 64) rc = vq_launch_search<64>(x, codebook, row_mask, pr, n_rows, k_bins, (long long*)idx, min_dist, x_d, w, stream);
+  else rc = vq_launch_search<32>(x, codebook, row_mask, pr, n_rows, k_bins, (long long*)idx, min_dist, x_d, w, stream);
+  if (rc) return rc;
+  vq_reduce_kernel<<<1, 1024, 0, stream>>>(min_dist, row_mask, n_rows, pr.kmax2, sums);
   SMT_CHECK_LAUNCH("vq_reduce");
   return 0;
 }
 
-extern "C" int smt_vq_backward(const float* x, const float* codebook, const int64_t* idx, const float* row_mask,
-                               const float* dy, const float* g_commit, const float* sums, int64_t n_rows, int dim,
-                               float* dx, smt_stream_t stream_) {
+extern "C" int smt_vq_backward(const float* x, const float* x_d, const float* row_mask, const float* dy,
+                               const float* g_commit, const float* sums, int64_t n_rows, int dim, float* dx,
+                               smt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SMT_CHECK_ARG(dim % 4 == 0, "smt_vq_backward: dim must be a multiple of 4");
   if (n_rows == 0) return 0;
-  SMT_CHECK_ARG(x && codebook && idx && sums && dx, "smt_vq_backward: null pointer");
+  SMT_CHECK_ARG(x && x_d && sums && dx, "smt_vq_backward: null pointer");
   long long total4 = n_rows * dim / 4;
   unsigned grid = (unsigned)min((long long)2048, (total4 + 255) / 256);
-  vq_backward_kernel<<<grid, 256, 0, stream>>>(x, codebook, (const long long*)idx, row_mask, dy, g_commit, sums, n_rows,
-                                               dim, dx);
+  vq_backward_kernel<<<grid, 256, 0, stream>>>(x, x_d, row_mask, dy, g_commit, sums, n_rows, dim, dx);
   SMT_CHECK_LAUNCH("vq_backward");
   return 0;
 }
@@ -608,10 +853,17 @@ extern "C" int smt_vq_ema_accumulate(const float* x, const int64_t* idx, const f
 }
 
 extern "C" int smt_vq_ema_apply(float* codebook, float* k_sum, float* k_elem, const float* stats, const float* k_rand,
-                                float mu, float threshold, int k_bins, int dim, float* metrics, smt_stream_t stream_) {
+                                float mu, float threshold, int k_bins, int dim, float* metrics, void* prep,
+                                size_t prep_bytes, smt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  SMT_CHECK_ARG(codebook && k_sum && k_elem && stats && k_rand && metrics, "smt_vq_ema_apply: null pointer");
-  vq_ema_apply_kernel<<<1, 1024, 0, stream>>>(codebook, k_sum, k_elem, stats, k_rand, mu, threshold, k_bins, dim, metrics);
+  SMT_CHECK_ARG(codebook && k_sum && k_elem && stats && k_rand && metrics && prep, "smt_vq_ema_apply: null pointer");
+  SMT_CHECK_ARG(dim == 32 || dim == 64 || dim == 128, "smt_vq_ema_apply: dim must be 32, 64 or 128 (got %d)", dim);
+  SMT_CHECK_ARG(prep_bytes >= vq_prep_layout(k_bins, dim, nullptr, nullptr), "smt_vq_ema_apply: prep buffer too small");
+  VqPrep pr;
+  vq_prep_layout(k_bins, dim, prep, &pr);
+  vq_ema_apply_kernel<<<pr.nparts, 256, 0, stream>>>(codebook, k_sum, k_elem, stats, k_rand, mu, threshold, k_bins, dim,
+                                                     pr.part, pr.dkpart);
   SMT_CHECK_LAUNCH("vq_ema_apply");
-  return 0;
+  // the codebook has changed: refresh its centred split for the next forward in the same call
+  return vq_finish_prepare(codebook, k_bins, dim, pr, stats + (size_t)k_bins * dim, k_elem, threshold, metrics, stream);
 }

@@ -27,6 +27,23 @@ class BottleneckBlock(nn.Module):
         self.k_sum = None
         self.k_elem = None
         self.register_buffer("k", torch.zeros(self.k_bins, self.emb_width))
+        self._prep, self._prep_key = None, None
+
+    # -- derived data of the nearest-code search (centred bf16 split of the codes, norms): rebuilt only when `k`
+    #    changes.  update_k refreshes it inside smt_vq_ema_apply; every other writer of `k` invalidates it. ----------
+    def _invalidate_prep(self):
+        self._prep_key = None
+
+    def _search_prep(self):
+        key = (self.k.data_ptr(), self.k._version)
+        if self._prep_key != key:
+            self._prep = vq.prepare(self.k, self._prep)
+            self._prep_key = key
+        return self._prep
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self._invalidate_prep()
 
     # -- random rows for init / dead-code revival (bottleneck.py:26-33, :40, :69-70) -----------
     def _random_rows(self, rows, row_mask):
@@ -54,11 +71,13 @@ class BottleneckBlock(nn.Module):
         if dist.is_initialized():
             dist.broadcast(k_rand, 0)
         self.k = k_rand.clone()
+        self._invalidate_prep()
         self.k_sum = self.k.clone()
         self.k_elem = torch.ones(self.k_bins, device=self.k.device)
 
     def restore_k(self, num_tokens=None, threshold=1.0):
         self.init = True
+        self._invalidate_prep()
         self.k_sum = self.k.clone()
         self.k_elem = torch.ones(self.k_bins, device=self.k.device)
         if num_tokens is not None:
@@ -79,14 +98,16 @@ class BottleneckBlock(nn.Module):
             revival.zero_()
         if dist.is_initialized():
             dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-        m = vq.ema_apply(self.k, self.k_sum, self.k_elem, stats, revival, self.mu, self.threshold)
+        m, self._prep = vq.ema_apply(self.k, self.k_sum, self.k_elem, stats, revival, self.mu, self.threshold, self._prep)
+        self._prep_key = (self.k.data_ptr(), self.k._version)     # written by pointer: the version did not move
         return dict(entropy=m[0], used_curr=m[1], usage=m[2], dk=m[3])
 
     @torch.no_grad()
     def encode(self, x, lens):
         """x [B, T, D] -> codes [B, T] (bottleneck.py:147-158)."""
         b, t, d = x.shape
-        idx, _, _, _ = vq.vq_forward_raw(x.reshape(b * t, d).float().contiguous(), self.k, None, want_xd=False)
+        idx, _, _, _ = vq.vq_forward_raw(x.reshape(b * t, d).float().contiguous(), self.k, None, want_xd=False,
+                                         prep=self._search_prep())
         return idx.view(b, t)
 
     def decode(self, codes):
@@ -100,8 +121,9 @@ class BottleneckBlock(nn.Module):
         row_mask = (steps[None, :] < lens[:, None]).to(torch.float32).reshape(b * t)
         if update_k and not self.init:
             self.init_k(rows.detach(), row_mask, k_rand_init)
-        codebook = self.k.clone() if update_k else self.k  # update_k rewrites self.k in place
-        x_d, idx, commit, fit = vq.vq_straight_through(rows, codebook, row_mask, detach_quantised=False)
+        # update_k rewrites self.k in place afterwards; backward reads the quantised rows from x_d, not from k
+        x_d, idx, commit, fit = vq.vq_straight_through(rows, self.k, row_mask, detach_quantised=False,
+                                                       prep=self._search_prep())
         metrics = dict(fit=fit)
         if update_k:
             metrics.update(self.update_k(rows.detach(), idx, row_mask, k_rand))

@@ -7,7 +7,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsmt_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 _lock = threading.Lock()
@@ -23,11 +23,14 @@ _SIGNATURES = {
     "smt_last_error": (ctypes.c_char_p, []),
     "smt_abi_version": (c_int, []),
     "smt_vq_forward_workspace_bytes": (c_size, [c_i64, c_int, c_int]),
-    "smt_vq_forward": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size,
+    "smt_vq_prep_bytes": (c_size, [c_int, c_int]),
+    "smt_vq_prepare": (c_int, [c_ptr, c_int, c_int, c_ptr, c_size, c_ptr]),
+    "smt_vq_forward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size,
                                c_ptr]),
-    "smt_vq_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
+    "smt_vq_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
     "smt_vq_ema_accumulate": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr]),
-    "smt_vq_ema_apply": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_int, c_int, c_ptr, c_ptr]),
+    "smt_vq_ema_apply": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_int, c_int, c_ptr, c_ptr, c_size,
+                                 c_ptr]),
     "smt_pack_weight": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_ptr, c_int, c_ptr]),
     "smt_pack_weights_batched": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_ptr]),
     "smt_conv1d_ntc": (c_int, [c_ptr, c_ptr]),

@@ -9,9 +9,23 @@ from . import native as N
 from . import profiler
 
 
-def vq_forward_raw(x, codebook, row_mask=None, want_xd=True):
+def prepare(codebook, prep=None):
+    """Derived data of the nearest-code search for THIS codebook content (include/smt_hip.h, smt_vq_prepare): returns
+    the persistent buffer to hand to vq_forward_raw / vq_straight_through / ema_apply."""
+    assert codebook.dtype == torch.float32 and codebook.is_cuda
+    k, d = codebook.shape
+    lib = N.lib()
+    nbytes = lib.smt_vq_prep_bytes(k, d)
+    if prep is None or prep.numel() < nbytes or prep.device != codebook.device:
+        prep = torch.empty(nbytes, dtype=torch.uint8, device=codebook.device)
+    N.check(lib.smt_vq_prepare(N.ptr(codebook), k, d, N.ptr(prep), prep.numel(), N.stream_ptr()), "smt_vq_prepare")
+    return prep
+
+
+def vq_forward_raw(x, codebook, row_mask=None, want_xd=True, prep=None):
     """x [n, D] f32, codebook [K, D] f32, row_mask [n] f32|None ->
-    (idx int64 [n], min_dist f32 [n], x_d f32 [n, D]|None, sums f32 [4])."""
+    (idx int64 [n], min_dist f32 [n], x_d f32 [n, D]|None, sums f32 [4]).  ``prep`` = prepare(codebook) of the same
+    codebook content (None: rebuilt inside the call)."""
     assert x.dtype == torch.float32 and codebook.dtype == torch.float32
     n, d = x.shape
     k = codebook.shape[0]
@@ -24,8 +38,9 @@ def vq_forward_raw(x, codebook, row_mask=None, want_xd=True):
     ws = N.workspace.get(ws_bytes, x.device)
     # algorithmic bytes: 4D read + 8 idx + 4 min_dist (+ 4D x_d) per row, + codebook once
     nbytes = n * (4 * d + 12 + (4 * d if want_xd else 0)) + 4 * k * d
-    with profiler.region("vq_forward", nbytes=nbytes, flops=2.0 * n * k * d, bound="hbm"):
-        N.check(lib.smt_vq_forward(N.ptr(x), N.ptr(codebook), N.ptr(row_mask), n, k, d, N.ptr(idx),
+    # flops: the filter's three bf16 MFMA products per (row, code, dim) -- the work the kernel really issues
+    with profiler.region("vq_forward", nbytes=nbytes, flops=3 * 2.0 * n * k * d, bound="hbm", dtype="bf16"):
+        N.check(lib.smt_vq_forward(N.ptr(x), N.ptr(codebook), N.ptr(prep), N.ptr(row_mask), n, k, d, N.ptr(idx),
                                    N.ptr(min_dist), N.ptr(x_d), N.ptr(sums), N.ptr(ws), ws.numel(),
                                    N.stream_ptr()), "smt_vq_forward")
     return idx, min_dist, x_d, sums
@@ -33,17 +48,18 @@ def vq_forward_raw(x, codebook, row_mask=None, want_xd=True):
 
 class _VQStraightThrough(torch.autograd.Function):
     """(x, codebook, row_mask) -> (x_d*mask, idx, commit, fit); backward = straight-through
-    + commit-loss gradient (bottleneck.py:194-201)."""
+    + commit-loss gradient (bottleneck.py:194-201).  Backward reads the quantised rows from x_d, not from the
+    codebook, so the caller may rewrite the codebook in place (update_k) before backward runs."""
 
     @staticmethod
-    def forward(ctx, x, codebook, row_mask, detach_quantised):
+    def forward(ctx, x, codebook, row_mask, detach_quantised, prep):
         x = x.contiguous()
-        idx, min_dist, x_d, sums = vq_forward_raw(x, codebook, row_mask)
+        idx, min_dist, x_d, sums = vq_forward_raw(x, codebook, row_mask, prep=prep)
         n, d = x.shape
         k = codebook.shape[0]
         commit = sums[1] / (sums[2] * d)          # ||x_d - x||^2 over unmasked rows / (sum mask * D)
         fit = sums[0] / k                         # reference's [N]*[N,1] broadcast: sum over ALL rows / K
-        ctx.save_for_backward(x, codebook, idx, row_mask if row_mask is not None else torch.empty(0), sums)
+        ctx.save_for_backward(x, x_d, row_mask if row_mask is not None else torch.empty(0), sums)
         ctx.has_mask = row_mask is not None
         ctx.detach_quantised = detach_quantised
         ctx.mark_non_differentiable(idx, fit)
@@ -51,20 +67,20 @@ class _VQStraightThrough(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_xd, g_idx, g_commit, g_fit):
-        x, codebook, idx, row_mask, sums = ctx.saved_tensors
+        x, x_d, row_mask, sums = ctx.saved_tensors
         row_mask = row_mask if ctx.has_mask else None
         n, d = x.shape
         dy = None if (g_xd is None or ctx.detach_quantised) else g_xd.contiguous()
         gc = None if g_commit is None else g_commit.reshape(1).to(torch.float32).contiguous()
         dx = torch.empty_like(x)
         lib = N.lib()
-        N.check(lib.smt_vq_backward(N.ptr(x), N.ptr(codebook), N.ptr(idx), N.ptr(row_mask), N.ptr(dy), N.ptr(gc),
-                                    N.ptr(sums), n, d, N.ptr(dx), N.stream_ptr()), "smt_vq_backward")
-        return dx, None, None, None
+        N.check(lib.smt_vq_backward(N.ptr(x), N.ptr(x_d), N.ptr(row_mask), N.ptr(dy), N.ptr(gc), N.ptr(sums), n, d,
+                                    N.ptr(dx), N.stream_ptr()), "smt_vq_backward")
+        return dx, None, None, None, None
 
 
-def vq_straight_through(x, codebook, row_mask=None, detach_quantised=False):
-    return _VQStraightThrough.apply(x, codebook, row_mask, detach_quantised)
+def vq_straight_through(x, codebook, row_mask=None, detach_quantised=False, prep=None):
+    return _VQStraightThrough.apply(x, codebook, row_mask, detach_quantised, prep)
 
 
 def ema_stats_numel(k_bins, dim):
@@ -82,11 +98,17 @@ def ema_accumulate(x, idx, row_mask, k_bins, stats):
 
 
 @torch.no_grad()
-def ema_apply(codebook, k_sum, k_elem, stats, k_rand, mu, threshold):
+def ema_apply(codebook, k_sum, k_elem, stats, k_rand, mu, threshold, prep=None):
+    """In-place update of codebook / k_sum / k_elem; ``prep`` (see prepare) is refreshed for the new codebook in the
+    same call.  Returns (metrics [4], prep)."""
     k, d = codebook.shape
     metrics = torch.empty(4, dtype=torch.float32, device=codebook.device)
     lib = N.lib()
-    N.check(lib.smt_vq_ema_apply(N.ptr(codebook), N.ptr(k_sum), N.ptr(k_elem), N.ptr(stats), N.ptr(k_rand),
-                                 float(mu), float(threshold), k, d, N.ptr(metrics), N.stream_ptr()),
-            "smt_vq_ema_apply")
-    return metrics
+    nbytes = lib.smt_vq_prep_bytes(k, d)
+    if prep is None or prep.numel() < nbytes or prep.device != codebook.device:
+        prep = torch.empty(nbytes, dtype=torch.uint8, device=codebook.device)
+    with profiler.region("vq_ema_apply", nbytes=4 * (5 * k * d + 3 * k), bound="hbm"):
+        N.check(lib.smt_vq_ema_apply(N.ptr(codebook), N.ptr(k_sum), N.ptr(k_elem), N.ptr(stats), N.ptr(k_rand),
+                                     float(mu), float(threshold), k, d, N.ptr(metrics), N.ptr(prep), prep.numel(),
+                                     N.stream_ptr()), "smt_vq_ema_apply")
+    return metrics, prep

@@ -88,7 +88,7 @@ def _cpu_vq_ops():
         stats[:k_bins * d].view(k_bins, d).index_add_(0, idx[sel], x[sel])
         stats[k_bins * d:k_bins * d + k_bins] += torch.bincount(idx[sel], minlength=k_bins).float()
 
-    def ema_apply(codebook, k_sum, k_elem, stats, k_rand, mu, threshold):
+    def ema_apply(codebook, k_sum, k_elem, stats, k_rand, mu, threshold, prep=None):
         kb, d = codebook.shape
         state = orc.CodebookState(k=codebook.clone(), k_sum=k_sum.clone(), k_elem=k_elem.clone(), init=True)
         _k_sum, _k_elem = stats[:kb * d].view(kb, d), stats[kb * d:kb * d + kb]
@@ -100,7 +100,7 @@ def _cpu_vq_ops():
         codebook.copy_(state.k); k_sum.copy_(state.k_sum); k_elem.copy_(state.k_elem)
         prob = _k_elem / _k_elem.sum()
         return torch.stack([-(prob * orc.safe_log(prob)).sum(), (_k_elem >= threshold).sum().float(), usage.sum(),
-                            torch.norm(state.k - old_k) / np.sqrt(kb * d)])
+                            torch.norm(state.k - old_k) / np.sqrt(kb * d)]), prep
     return ema_accumulate, ema_apply
 
 

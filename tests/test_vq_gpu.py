@@ -111,7 +111,12 @@ def test_forward_backward_update_k_match_reference(golden):
         stats = torch.empty(vq.ema_stats_numel(kb, d), device="cuda")
         vq.ema_accumulate(x.detach(), idx, row_mask, kb, stats)
         stats[kb * d + kb:] = dev(g[f"s{step}_k_rand"]).reshape(-1)
-        metrics = vq.ema_apply(k, k_sum, k_elem, stats, stats[kb * d + kb:], float(g["mu"]), float(g["threshold"]))
+        metrics, prep = vq.ema_apply(k, k_sum, k_elem, stats, stats[kb * d + kb:], float(g["mu"]), float(g["threshold"]))
+        # the prep refreshed by ema_apply serves the next search exactly like a freshly prepared one
+        i_a, _, _, _ = vq.vq_forward_raw(x.detach(), k, row_mask, prep=prep)
+        i_b, _, _, _ = vq.vq_forward_raw(x.detach(), k, row_mask, prep=vq.prepare(k))
+        i_c, _, _, _ = vq.vq_forward_raw(x.detach(), k, row_mask)
+        assert torch.equal(i_a, i_b) and torch.equal(i_a, i_c)
         torch.cuda.synchronize()
         for name, tns in (("k", k), ("k_sum", k_sum), ("k_elem", k_elem)):
             assert torch.allclose(tns.cpu(), T(g[f"s{step}_{name}"]), atol=1e-5), name

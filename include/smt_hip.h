@@ -91,6 +91,19 @@ int smt_vq_ema_apply(float* codebook, float* k_sum, float* k_elem, const float* 
                      float* metrics, void* prep, size_t prep_bytes, smt_stream_t stream);
 
 
+/* --------------------------------------------------------------- losses ---- */
+/* MultiNormReconstructionLoss (models/vqvae/losses.py:73-80) on [batch, t] fp32 signals, d = (y - yh) * [i < lens[b]]:
+ * per clip the plain sums and the sum of the `topk` largest d^2 (exact k-th-largest threshold by radix select; the
+ * reference materialises d^2 and calls torch.topk).  stats [batch][8] f32 =
+ *   {sum d^2, sum |d|, sum of the topk largest d^2, threshold tau, #(d^2 > tau), #(d^2 == tau), 0, 0};
+ * loss = l1 * sum_b stats[b][1] / (B t) + l2 * sum_b stats[b][0] / (B t) + linf * sum_b stats[b][2] / B (host side). */
+int smt_recon_loss_fwd(const float* y, const float* yh, const int* lens, int batch, int t, int topk, float* stats,
+                       smt_stream_t stream);
+/* d loss / d yh given the stats of the forward and coef [3] (device) = upstream gradient times
+ * {l1 / (B t), 2 l2 / (B t), 2 linf / B}. */
+int smt_recon_loss_bwd(const float* y, const float* yh, const int* lens, const float* stats, const float* coef,
+                       int batch, int t, int topk, float* dyh, smt_stream_t stream);
+
 /* ------------------------------------------------------------ conv stack ---- */
 /* Counter-based dropout ("dropout" spec).  The reference draws dropout masks from torch's global
  * RNG (models/vqvae/resnet.py:22,25), which no other device can reproduce; this build defines a

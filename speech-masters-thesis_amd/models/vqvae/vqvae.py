@@ -88,3 +88,13 @@ class VQVAE(WaveformReconstructionModel):
         b, _, t = x.shape
         z, z_lens = self.encoders[0](x.reshape(b, t), x_lengths.to(torch.int32))
         return self.bottleneck.level_blocks[0].encode(z.float(), z_lens), z_lens
+
+    @torch.no_grad()
+    def dequantize_and_decode(self, q, q_lengths):
+        """codes [B, T'] + lengths -> masked reconstruction [B, 1, T] (scripts/generate_vq_dataset.py:72-80)."""
+        z_lens = q_lengths.to(torch.int32)
+        xq = self.bottleneck.level_blocks[0].decode(q)
+        keep = (torch.arange(q.shape[1], device=q.device)[None, :] < z_lens[:, None]).unsqueeze(-1)
+        y, y_lens = self.decoders[0]((xq * keep).to(self.compute_dtype), z_lens)
+        keep_t = torch.arange(y.shape[1], device=y.device)[None, :] < y_lens[:, None]
+        return (y * keep_t).unsqueeze(1)

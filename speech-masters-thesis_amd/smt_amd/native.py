@@ -55,6 +55,8 @@ _SIGNATURES = {
                                   c_int, c_ptr, c_size, c_ptr]),
     "smt_conv_out_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "smt_conv_out_bwd_workspace_bytes": (c_size, [c_int, c_int, c_int]),
+    "smt_recon_loss_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr]),
+    "smt_recon_loss_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr]),
     "smt_stft_num_frames": (c_int, [c_int, c_int, c_int]),
     "smt_stft_magnitude": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "smt_melspec": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr]),

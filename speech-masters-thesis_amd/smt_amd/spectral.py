@@ -104,3 +104,42 @@ class _StftLoss(torch.autograd.Function):
 
 def stft_loss(y, yh, lens, n_fft, hop, win_length, use_log):
     return _StftLoss.apply(y, yh, lens, n_fft, hop, win_length, use_log)
+
+
+class _ReconLoss(torch.autograd.Function):
+    """l1 * mean|d| + l2 * mean d^2 + linf * sum_j mean_b topk_j(d^2) on masked [B, T] signals (losses.py:73-80)."""
+
+    @staticmethod
+    def forward(ctx, y, yh, lens, l1, l2, linf, topk):
+        y, yh = y.contiguous().float(), yh.contiguous().float()
+        b, t = y.shape
+        lens32 = None if lens is None else lens.to(torch.int32)
+        stats = torch.empty(b, 8, dtype=torch.float32, device=y.device)
+        with profiler.region("recon_loss_fwd", nbytes=5 * 2 * y.numel() * 4, bound="hbm"):
+            N.check(N.lib().smt_recon_loss_fwd(N.ptr(y), N.ptr(yh), N.ptr(lens32), b, t, int(topk), N.ptr(stats),
+                                               N.stream_ptr()), "smt_recon_loss_fwd")
+        sums = stats[:, :3].sum(dim=0)                 # fixed-order reduction over the batch
+        loss = l2 * sums[0] / (b * t) + linf * sums[2] / b
+        if l1:
+            loss = loss + l1 * sums[1] / (b * t)
+        ctx.save_for_backward(y, yh, lens32 if lens32 is not None else torch.empty(0), stats)
+        ctx.cfg = (l1, l2, linf, int(topk), lens is not None)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        y, yh, lens32, stats = ctx.saved_tensors
+        l1, l2, linf, topk, has_lens = ctx.cfg
+        lens32 = lens32 if has_lens else None
+        b, t = y.shape
+        scale = torch.tensor([l1 / (b * t), 2.0 * l2 / (b * t), 2.0 * linf / b], dtype=torch.float32, device=y.device)
+        coef = (g.reshape(1).float() * scale).contiguous()
+        dyh = torch.empty_like(yh)
+        with profiler.region("recon_loss_bwd", nbytes=3 * y.numel() * 4, bound="hbm"):
+            N.check(N.lib().smt_recon_loss_bwd(N.ptr(y), N.ptr(yh), N.ptr(lens32), N.ptr(stats), N.ptr(coef), b, t, topk,
+                                               N.ptr(dyh), N.stream_ptr()), "smt_recon_loss_bwd")
+        return None, dyh, None, None, None, None, None
+
+
+def recon_loss(y, yh, lens, l1, l2, linf, topk):
+    return _ReconLoss.apply(y, yh, lens, float(l1), float(l2), float(linf), int(topk))

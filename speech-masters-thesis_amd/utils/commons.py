@@ -53,7 +53,7 @@ def get_model(config, device="cuda:0", rank=0):
     return model, ema
 
 
-def get_dataloaders(config, rank=0, world_size=1):
+def get_dataloaders(config, rank=0, world_size=1, shuffle_train=True):
     from torch.utils.data import DataLoader
     from torch.utils.data.distributed import DistributedSampler
     dataset = _resolve(config.dataset["_import_"])
@@ -64,7 +64,7 @@ def get_dataloaders(config, rank=0, world_size=1):
         sampler = DistributedSampler(train_set, num_replicas=world_size, rank=rank, shuffle=True)
         train_loader = DataLoader(train_set, sampler=sampler, **common)
     else:
-        train_loader = DataLoader(train_set, shuffle=True, **common)
+        train_loader = DataLoader(train_set, shuffle=shuffle_train, **common)
     val_loader = DataLoader(dataset(config, split="val"), **common) if rank == 0 else None
     return train_loader, val_loader
 

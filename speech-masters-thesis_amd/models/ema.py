@@ -61,3 +61,5 @@ class EMA(nn.Module):
             tmp = p.detach().float().clone()
             p.copy_(s.to(p.dtype))
             s.copy_(tmp)
+        from smt_amd import convops
+        convops.invalidate_packed_weights()       # belt and braces: copy_ bumps the version, foreign writers might not

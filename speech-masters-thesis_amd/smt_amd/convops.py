@@ -171,6 +171,16 @@ class _PackCache:
 _pack_cache = _PackCache()
 
 
+def invalidate_packed_weights():
+    """Forget every packed operand copy.  The cache notices in-place updates through ``Tensor._version`` (optimiser
+    steps, ``copy_``, ``broadcast``); writes that bypass the version counter -- ``p.data.copy_(...)`` as in the
+    reference's ``EMA.swap`` (models/ema.py:60-66), or a foreign kernel writing the parameter by pointer -- do not
+    bump it, so such writers call this afterwards (``load_checkpoint`` and ``EMA.swap`` do)."""
+    _pack_cache.entries.clear()
+    _pack_cache.order.clear()
+    _pack_cache.table = None
+
+
 def _pack_parts(parts, dtype, dst_shape):
     """parts: [(weight, n_out, n_in, s_out, s_in, s_tap, tap_map, swizzle, dst_offset, dst_tap_stride, dst_row_stride)]
     packed side by side into one operand of shape dst_shape; cached (see _PackCache)."""

@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))  # ahead of any p
 from utils import config as cfglib  # noqa: E402
 from utils.commons import get_dataloaders, get_model, get_optimizer, setup_logdir, to_device  # noqa: E402
 from utils.train_utils import (ScalarWriter, accumulate_stats, barrier, log_stats,  # noqa: E402
-                               print_top_level_summary, save_checkpoint, seed_all_rng)
+                               print_top_level_summary, restore_extra_train_state, save_checkpoint, seed_all_rng)
 
 logging.basicConfig(level=logging.INFO, format="%(asctime)s %(name)s %(levelname)s: %(message)s")
 logger = logging.getLogger("train")
@@ -139,6 +139,9 @@ def train(*, global_step, epoch, config, model, ema, optimizer, scheduler, train
 def load_checkpoint(path, model, optimizer, scheduler, ema, device):
     ckpt = torch.load(path, map_location=device, weights_only=True)
     model.load_state_dict(ckpt["model"])
+    restore_extra_train_state(model, ckpt.get("extra"))     # codebook accumulators, dropout counter (or restore_k)
+    from smt_amd import convops
+    convops.invalidate_packed_weights()
     optimizer.load_state_dict(ckpt["optim"])
     scheduler.load_state_dict(ckpt["sched"])
     ema.load_state_dict(ckpt["ema"])

@@ -87,8 +87,44 @@ def save_checkpoint(config, global_step, epoch, model, ema, optimizer, scheduler
         "ema": ema.state_dict(),
         "step": global_step,
         "epoch": config.train.total_epochs if epoch == -1 else epoch,
+        # not in the reference's checkpoints (train_utils.py:148-171): the codebook's EMA accumulators and the dropout step
+        # counter are plain attributes there and are lost on resume (bottleneck.py:20-24,179); loaders tolerate the key
+        "extra": extra_train_state(model),
     }, path)
     return path
+
+
+def extra_train_state(model):
+    """Training state that lives outside ``state_dict()``: per codebook ``k_sum`` / ``k_elem`` / ``init``, and the
+    dropout step counter."""
+    out = {}
+    bottleneck = getattr(model, "bottleneck", None)
+    for i, blk in enumerate(getattr(bottleneck, "level_blocks", [])):
+        if getattr(blk, "init", False) and blk.k_sum is not None:
+            out[f"bottleneck.level_blocks.{i}"] = {"k_sum": blk.k_sum.detach().clone(), "k_elem": blk.k_elem.detach().clone(),
+                                                   "threshold": float(blk.threshold)}
+    if hasattr(model, "_drop_seed"):
+        out["drop_seed"] = int(model._drop_seed)
+    return out
+
+
+def restore_extra_train_state(model, extra):
+    """Counterpart of ``extra_train_state``.  Without the extra entry (a checkpoint written by the reference) a codebook
+    that was trained (non-zero ``k``) is kept with ``restore_k()`` (bottleneck.py:48-58) instead of being re-drawn from
+    the first batch, which is what the reference's resume path silently does (``init`` is False after loading)."""
+    extra = extra or {}
+    bottleneck = getattr(model, "bottleneck", None)
+    for i, blk in enumerate(getattr(bottleneck, "level_blocks", [])):
+        st = extra.get(f"bottleneck.level_blocks.{i}")
+        if st is not None:
+            blk.k_sum = st["k_sum"].to(blk.k.device, torch.float32).clone()
+            blk.k_elem = st["k_elem"].to(blk.k.device, torch.float32).clone()
+            blk.threshold = float(st.get("threshold", blk.threshold))
+            blk.init = True
+        elif bool(blk.k.abs().sum() > 0):
+            blk.restore_k(threshold=blk.threshold)
+    if "drop_seed" in extra and hasattr(model, "_drop_seed"):
+        model._drop_seed = int(extra["drop_seed"])
 
 
 def print_top_level_summary(model):

@@ -245,6 +245,7 @@ def randomize(module, g, scale=1.0):
 
 def gen_block():
     g = torch.Generator().manual_seed(41)
+    torch.manual_seed(41)           # the module constructor draws from the GLOBAL generator: seed it, so the fixture regenerates
     blk = GatedHiFiBlock(16, 4, dilation_growth_rate=3, kernel_size_growth_rate=2, zero_out=True)
     randomize(blk, g)
     blk.eval()
@@ -416,6 +417,7 @@ def gen_losses():
 # ---- G8: parameter EMA (models/ema.py:24-66) -----------------------------------------
 def gen_ema():
     g = torch.Generator().manual_seed(91)
+    torch.manual_seed(91)           # nn.Linear's init draws from the global generator
     lin = torch.nn.Linear(5, 3)
     ema = EMA(lin, mu=0.9)
     out = {"w0": lin.weight.detach().clone(), "b0": lin.bias.detach().clone()}

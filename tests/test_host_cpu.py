@@ -160,7 +160,8 @@ def test_optimizer_scheduler_ema_and_checkpoint_layout(tmp_path):
     assert opt.param_groups[0]["lr"] == 1e-4                                                   # DummyLR: constant
     path = save_checkpoint(cfg, 12, 1, model, ema, opt, sched)
     ckpt = torch.load(path, weights_only=True)
-    assert set(ckpt) == {"config", "model", "optim", "sched", "ema", "step", "epoch"} and ckpt["step"] == 12
+    # the reference's seven keys (train_utils.py:148-171) + "extra" (codebook accumulators / dropout counter, tolerated by loaders)
+    assert set(ckpt) == {"config", "model", "optim", "sched", "ema", "step", "epoch", "extra"} and ckpt["step"] == 12
     assert os.path.basename(save_checkpoint(cfg, 99, -1, model, ema, opt, sched)) == "ckpt.last.pt"
     losses, metrics = defaultdict(float), defaultdict(float)
     accumulate_stats(2, {"loss": torch.tensor(4.0), "loss_x": torch.tensor(2.0), "yh": torch.zeros(3)},

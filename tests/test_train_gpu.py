@@ -41,3 +41,64 @@ def test_train_two_epochs_checkpoint_and_resume(tmp_path, monkeypatch):
     finally:
         os.remove("configs/models/_test_small.yaml")
         os.remove("configs/datasets/_test_small.yaml")
+
+
+def test_resume_keeps_the_trained_codebook(tmp_path):
+    """save -> load -> one train step: the codebook moves by an EMA-sized step instead of being re-drawn from
+    the batch (the reference's resume path re-initialises it: bottleneck.py:179 with init lost on load); the dropout
+    counter continues; a reference-style checkpoint without the extra entry is kept alive with restore_k()."""
+    import train as trainlib
+    from oracle import vqvae_oracle as orc
+    from utils import config as C
+    from utils.commons import get_model, get_optimizer
+    from utils.train_utils import save_checkpoint
+    root = PKG
+    cfg = C.merge(C.load(os.path.join(root, "configs/models/vqvae.yaml")),
+                  C.load(os.path.join(root, "configs/datasets/synthetic_ljspeech.yaml")),
+                  C.create({"train": {"batch_size": 2, "n_gpus": 1, "ema": True, "grad_clip_norm": None, "seed": 0,
+                                      "log_dir": str(tmp_path), "total_epochs": 1}}))
+    cfg.model.update(C.create(dict(width=16, emb_width=32, l_bins=64, multipliers=[1, 1, 1])))
+    cfg.model.loss.linf_topk = 128
+    os.makedirs(tmp_path / "ckpts")
+    dev = torch.device("cuda", 0)
+
+    def fresh():
+        torch.manual_seed(0)
+        m, e = get_model(C.create(cfg.to_dict()), dev)
+        o, s = get_optimizer(cfg, m)
+        return m, e, o, s
+
+    x = orc.synthetic_clip_batch(2, 8192, 5).cuda()
+    lens = torch.tensor([8192, 6144]).cuda()
+    batch = [None, None, None, None, x, lens, None]
+    model, ema, opt, sched = fresh()
+    model.train()
+    for step in range(3):
+        trainlib.train_step(global_step=step, batch=batch, config=cfg, model=model, ema=ema, optimizer=opt, scheduler=sched,
+                            device=dev)
+    blk = model.bottleneck.level_blocks[0]
+    k_trained, seed_trained = blk.k.clone(), model._drop_seed
+    path = save_checkpoint(cfg, 3, 0, model, ema, opt, sched)
+
+    m2, e2, o2, s2 = fresh()
+    step, epoch = trainlib.load_checkpoint(path, m2, o2, s2, e2, dev)
+    b2 = m2.bottleneck.level_blocks[0]
+    assert (step, epoch) == (3, 0) and b2.init and m2._drop_seed == seed_trained
+    assert torch.equal(b2.k, k_trained) and torch.equal(b2.k_sum, blk.k_sum) and torch.equal(b2.k_elem, blk.k_elem)
+    m2.train()
+    trainlib.train_step(global_step=3, batch=batch, config=cfg, model=m2, ema=e2, optimizer=o2, scheduler=s2, device=dev)
+    trainlib.train_step(global_step=3, batch=batch, config=cfg, model=model, ema=ema, optimizer=opt, scheduler=sched, device=dev)
+    # the resumed run continues exactly like the uninterrupted one (same dropout seed, same accumulators) ...
+    assert torch.allclose(b2.k, blk.k, atol=1e-6) and torch.allclose(b2.k_sum, blk.k_sum, atol=1e-5)
+    # ... and the codebook moved by an EMA-sized step, it was not re-drawn
+    moved = (b2.k - k_trained).norm() / k_trained.norm()
+    assert 0 < moved < 0.2, moved
+
+    # a checkpoint without the extra entry (what the reference writes)
+    ck = torch.load(path, weights_only=True)
+    ck.pop("extra")
+    torch.save(ck, tmp_path / "ckpts" / "ckpt.ref.pt")
+    m3, e3, o3, s3 = fresh()
+    trainlib.load_checkpoint(str(tmp_path / "ckpts" / "ckpt.ref.pt"), m3, o3, s3, e3, dev)
+    b3 = m3.bottleneck.level_blocks[0]
+    assert b3.init and torch.equal(b3.k, k_trained) and torch.equal(b3.k_sum, k_trained) and bool((b3.k_elem == 1).all())

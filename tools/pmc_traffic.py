@@ -21,7 +21,8 @@ GROUPS = [  # (key, substrings of the kernel name)
     ("conv_wgrad_shift_kernel", ["conv_wgrad_shift_kernel"]),
     ("conv_wgrad", ["conv_wgrad_kernel", "conv_wgrad_dma_kernel", "conv_wgrad_reduce_kernel"]),
     ("gate_mix", ["gate_mix_fwd_kernel", "gate_mix_bwd_kernel"]),
-    ("vq_forward", ["vq_mean", "vq_prep", "vq_score", "vq_finalize", "vq_rescore", "vq_reduce"]),
+    ("vq_forward", ["vq_search", "vq_candidates", "vq_exact", "vq_reduce"]),
+    ("recon_loss", ["recon_loss_fwd", "recon_loss_bwd"]),
 ]
 
 

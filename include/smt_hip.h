@@ -214,6 +214,17 @@ int smt_conv_k1_bwd(const void* dh, int64_t bs_dh, int ld_dh, const void* x, int
                     int64_t stride_out, int64_t stride_in, float* dbias, void* workspace, size_t workspace_bytes,
                     smt_stream_t stream);
 
+/* K3 of all four branches of a GatedHiFiBlock + the tanh * softmax gate in one pass (bf16, width 64; resnet.py:224-237):
+ *   z[b,t,128 d + c] = b3[d][c] + sum_i W3_d[c][i] u2[b,t,128 d + i]  +  b1[d][c] + sum_j W1_d[c][j] x[b,t,j]     d = 0..3
+ *   g[b,t,c]         = sum_d tanh(z[.., 128 d + c]) * softmax_d(z[.., 128 d + 64 + c])                             c < 64
+ * u2 / z are [B,t,512], x / g [B,t,64] with explicit pitches; x rows >= lens[b] read as zero (lens may be NULL).
+ * w3_packed = the four [128][128] weights stacked, smt_pack_weight layout with swizzle = 1; w1_packed = the four [128][64]
+ * weights stacked, swizzle 0; b3 / b1 [4][128] fp32.  g is bit-identical to smt_conv1d_ntc (folded K3) + smt_gate_mix_fwd. */
+int smt_conv_k3gate_fwd(const void* u2, int64_t bs_u2, int ld_u2, const void* x, int64_t bs_x, int ld_x,
+                        const void* w3_packed, const void* w1_packed, const float* b3, const float* b1, void* z,
+                        int64_t bs_z, int ld_z, void* g, int64_t bs_g, int ld_g, const int* lens, int batch, int t,
+                        const void* zero_page, smt_stream_t stream);
+
 /* Fused backward of the 64 -> 64 1x1 gate convolution that closes a GatedHiFiBlock (bf16; resnet.py:238-241):
  * dx[t,ci] = keep(t) * sum_co dy[t,co] * W[co][ci] (keep = t < lens[b]), dweight[co*stride_out + ci*stride_in] =
  * sum_t dy[t,co] * g[t,ci] (g rows >= lens[b] read as 0), dbias[co] = sum_t dy[t,co].  dy / g / dx are [B,t,64] with

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void gate_mix_fwd_kernel(const T* __restrict__
       for (int d = 0; d < GM_MAX_DEPTH; ++d) if (d < depth) {
         float ex = __expf(sv[d][e] - m);
         den += ex;
-        num += ex * tanhf(tv[d][e]);
+        num += ex * gate_tanh(tv[d][e]);
       }
       out.v[e] = (T)(num / den);
     }
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void gate_mix_bwd_kernel(const T* __restrict__
         gv = *reinterpret_cast<const Vec<T, EPV>*>(dg + row * ldg + c);
       }
 #pragma unroll
-      for (int e = 0; e < EPV; ++e) { th[e] = tanhf((float)a.v[e]); sx[e] = (float)bb.v[e]; go[e] = (float)gv.v[e]; }
+      for (int e = 0; e < EPV; ++e) { th[e] = gate_tanh((float)a.v[e]); sx[e] = (float)bb.v[e]; go[e] = (float)gv.v[e]; }
     }
     Vec<T, EPV> dt, ds;
 #pragma unroll

@@ -224,6 +224,42 @@ def _pack_cat_fwd(weights, dtype):
     return _pack_parts(parts, dtype, (1, total, n_in))
 
 
+def _pack_cat_fwd_swz(weights, dtype):
+    """The same stack with the LDS-DMA chunk swizzle inside every [O_d][I] part (I a multiple of 128)."""
+    n_in = weights[0].shape[1]
+    total = sum(w.shape[0] for w in weights)
+    parts, row0 = [], 0
+    for w in weights:
+        parts.append((w, w.shape[0], n_in, n_in, 1, 1, [0], True, row0 * n_in, total * n_in, n_in))
+        row0 += w.shape[0]
+    return _pack_parts(parts, dtype, (1, total, n_in))
+
+
+def _cat_bias(biases):
+    """fp32 biases of several layers side by side, kept current by the pack cache (no torch.cat per step)."""
+    total = sum(b.shape[0] for b in biases)
+    parts, row0 = [], 0
+    for b in biases:
+        parts.append((b, b.shape[0], 1, 1, 1, 1, [0], False, row0, total, 1))
+        row0 += b.shape[0]
+    return _pack_parts(parts, torch.float32, (1, total, 1))
+
+
+_K3GATE = not bool(int(__import__("os").environ.get("SMT_NO_K3GATE", "0")))   # A/B switch for tests and profiles
+
+
+def _conv_k3gate(u2, x, w3p, w1p, b3, b1, z, g, lens32):
+    """K3 of the four branches + the gate in one pass (smt_conv_k3gate_fwd)."""
+    b, t = x.shape[0], x.shape[1]
+    (pu, bsu, ldu), (px, bsx, ldx_), (pz, bsz, ldz), (pg, bsg, ldg) = _geom(u2), _geom(x), _geom(z), _geom(g)
+    rows = float(b) * t
+    with profiler.region("conv_k3gate", flops=2.0 * rows * 512 * (128 + 64), nbytes=rows * (1024 + 128) * 2, bound="hbm",
+                         dtype="bf16"):
+        N.check(N.lib().smt_conv_k3gate_fwd(pu, bsu, ldu, px, bsx, ldx_, _p(w3p), _p(w1p), _p(b3), _p(b1), pz, bsz, ldz, pg,
+                                            bsg, ldg, _p(lens32), b, t, _p(_zero_page(x.device)), N.stream_ptr()),
+                "smt_conv_k3gate_fwd")
+
+
 def _pack_cat_bwd(weights, dtype):
     """Data-gradient operand [1][I][sum O_d] of the same stack (rows = input channels, columns = output channels)."""
     n_in = weights[0].shape[1]
@@ -656,7 +692,7 @@ class _GatedHiFi(torch.autograd.Function):
         # K1 for all branches at once.  On the LDS-DMA path (bf16, 2w == 128, w == 64) only the activated
         # output u1 is written: K3 recomputes its residual h1 = K1(x) + b1 from x (folded second term).
         fold = _dma_ok(dt, c2, c2) and c2 == 128 and w == 64
-        b1cat = torch.cat([p[1] for p in br], dim=0)
+        b1cat = _cat_bias([p[1] for p in br])
         u1 = torch.empty(b, t, depth * c2, dtype=dt, device=dev)
         h1 = None if fold else torch.empty_like(u1)
         d1 = _base_desc(x, h1, lens32, w, depth * c2, 1, 1, 1, 0, t, t_y=t)
@@ -679,7 +715,12 @@ class _GatedHiFi(torch.autograd.Function):
                 _use_dma(d2, wp2)
             _set_act_out(d2, u2_d, [specs[d][1][0]], thresh, scale, c2)
             _launch(d2, "conv_fwd", _conv_flops(d2), _conv_bytes(d2, x.element_size()))
-        for d in range(depth):
+        k3gate = fold and depth == 4 and _K3GATE
+        g = torch.empty(b, t, w, dtype=dt, device=dev)
+        if k3gate:     # K3 of the four branches + tanh * softmax gate in one pass: z is written once and never re-read here
+            _conv_k3gate(u2, x, _pack_cat_fwd_swz([p[4] for p in br], dt), _pack_cat_fwd([p[0] for p in br], dt),
+                         _cat_bias([p[5] for p in br]), b1cat, z, g, lens32)
+        for d in range(0 if k3gate else depth):
             sl = slice(d * c2, (d + 1) * c2)
             d3 = _base_desc(u2[:, :, sl], z[:, :, sl], None, c2, c2, 1, 1, 1, 0, t)
             dma = _dma_ok(dt, c2, c2)
@@ -696,10 +737,10 @@ class _GatedHiFi(torch.autograd.Function):
             _launch(d3, "conv_fwd", _conv_flops(d3) * (1.0 + (0.5 if fold else 0.0)),
                     _conv_bytes(d3, x.element_size()))
         del h1
-        g = torch.empty(b, t, w, dtype=dt, device=dev)
-        with profiler.region("gate_mix_fwd", nbytes=z.numel() * z.element_size() * 1.125, bound="hbm"):
-            N.check(N.lib().smt_gate_mix_fwd(_p(z), _p(g), _DT[dt], b * t, w, depth, depth * c2, w, N.stream_ptr()),
-                    "smt_gate_mix_fwd")
+        if not k3gate:
+            with profiler.region("gate_mix_fwd", nbytes=z.numel() * z.element_size() * 1.125, bound="hbm"):
+                N.check(N.lib().smt_gate_mix_fwd(_p(z), _p(g), _DT[dt], b * t, w, depth, depth * c2, w, N.stream_ptr()),
+                        "smt_gate_mix_fwd")
         out = torch.empty_like(x)
         dg_ = _base_desc(g, out, lens32, w, w, 1, 1, 1, 0, t)
         dg_.w, dg_.bias = _p(_pack_fwd(wg, dt)), _p(bg)

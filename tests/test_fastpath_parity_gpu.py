@@ -48,7 +48,7 @@ def kernel_names():
 # ------------------------------------------------------------------------------------------------------------
 # (a) block level
 # ------------------------------------------------------------------------------------------------------------
-FAST_FWD = {"conv_k1act:fwd", "conv_ws_pipe:fwd", "conv1x1_fold:fwd", "gate_mix_fwd"}
+FAST_FWD = {"conv_k1act:fwd", "conv_ws_pipe:fwd", "conv_k3gate"}
 FAST_BWD = {"conv_gate_bwd", "gate_mix_bwd", "conv1x1_bwd", "conv_ws:dgrad", "conv_wgrad_shift", "conv_k1_bwd"}
 
 
@@ -101,6 +101,40 @@ def test_gated_hifi_w64_fast_kernels_train_mode_vs_oracle(dtype):
     assert not bad, bad
     print(f"\n[w64 {dtype}] rel-L2: y {errs['y']:.2e} dx {errs['dx']:.2e} worst param grad "
           f"{max(v for k, v in errs.items() if k not in ('y', 'dx')):.2e}")
+
+
+def test_fused_k3_gate_kernel_is_bit_identical_to_the_unfused_path():
+    """smt_conv_k3gate_fwd (K3 of the four branches + tanh * softmax gate in one pass) against the four folded K3 launches
+    + gate_mix_fwd it replaces: same z, same g -> the block output and every gradient are bit-identical; ragged lens, a
+    row count that is not a multiple of the 128-row tile, train mode."""
+    from models.vqvae.resnet import GatedHiFiBlock
+    from smt_amd import convops, profiler
+    torch.manual_seed(3)
+    blk = GatedHiFiBlock(64, 4, dilation_growth_rate=3, kernel_size_growth_rate=2, zero_out=False, dropout=0.1,
+                         site_base=8).cuda().train()
+    g = torch.Generator().manual_seed(9)
+    b, t = 3, 5000 + 77
+    x = torch.randn(b, t, 64, generator=g).cuda().to(torch.bfloat16)
+    dy = torch.randn(b, t, 64, generator=g).cuda().to(torch.bfloat16)
+    lens = torch.tensor([t, 4000, 129], dtype=torch.int32).cuda()
+    outs = []
+    for fused in (True, False):
+        convops._K3GATE = fused
+        try:
+            xa = x.clone().requires_grad_(True)
+            blk.zero_grad()
+            profiler.reset(); profiler.enable(True)
+            y = blk(xa, lens, drop_seed=5)
+            y.backward(dy)
+            names = kernel_names()
+            profiler.enable(False); profiler.reset()
+        finally:
+            convops._K3GATE = True
+        assert ("conv_k3gate" in names) == fused and ("gate_mix_fwd" in names) == (not fused), sorted(names)
+        outs.append((y.detach().clone(), xa.grad.clone(), [p.grad.clone() for p in blk.parameters()]))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for a, c in zip(outs[0][2], outs[1][2]):
+        assert torch.equal(a, c)
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -104,6 +104,13 @@ int smt_recon_loss_fwd(const float* y, const float* yh, const int* lens, int bat
 int smt_recon_loss_bwd(const float* y, const float* yh, const int* lens, const float* stats, const float* coef,
                        int batch, int t, int topk, float* dyh, smt_stream_t stream);
 
+/* ------------------------------------------------------------------ MAS ---- */
+/* GlowTTS monotonic alignment search, `maximum_path` (models/glow_tts/submodules.py:28-67), on the device instead of the
+ * reference's numpy loop on the host: value / mask / path are [batch, t_x, t_y] fp32 (mask 0/1), max_neg_val = -inf in the
+ * reference's calls.  path is the 0/1 alignment, bit-identical to the numpy result. */
+int smt_maximum_path(const float* value, const float* mask, int batch, int t_x, int t_y, float max_neg_val, float* path,
+                     smt_stream_t stream);
+
 /* ------------------------------------------------------------ conv stack ---- */
 /* Counter-based dropout ("dropout" spec).  The reference draws dropout masks from torch's global
  * RNG (models/vqvae/resnet.py:22,25), which no other device can reproduce; this build defines a

@@ -57,6 +57,7 @@ _SIGNATURES = {
                                   c_int, c_ptr, c_size, c_ptr]),
     "smt_conv_out_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "smt_conv_out_bwd_workspace_bytes": (c_size, [c_int, c_int, c_int]),
+    "smt_maximum_path": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_f32, c_ptr, c_ptr]),
     "smt_recon_loss_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr]),
     "smt_recon_loss_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr]),
     "smt_stft_num_frames": (c_int, [c_int, c_int, c_int]),

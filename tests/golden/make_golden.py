@@ -448,12 +448,33 @@ def gen_ema():
     save("param_ema", **out)
 
 
+def gen_mas():
+    """models/glow_tts/submodules.py:28-67 `maximum_path`, the reference's own function.  It spells numpy's bool as
+    `np.bool`, an alias numpy >= 1.24 no longer has: restored in memory for the call (same meaning, nothing else touched)."""
+    from oracle import mas_oracle
+    if not hasattr(np, "bool"):
+        np.bool = bool
+    from models.glow_tts.submodules import maximum_path
+    g = torch.Generator().manual_seed(101)
+    b, t_x, t_y = 4, 37, 90
+    value = torch.randn(b, t_x, t_y, generator=g) * 3.0
+    x_len = torch.tensor([37, 20, 5, 1])
+    y_len = torch.tensor([90, 64, 3, 90])                  # item 2: fewer frames than tokens (the index wraps in numpy)
+    mask = ((torch.arange(t_x)[None, :, None] < x_len[:, None, None]) &
+            (torch.arange(t_y)[None, None, :] < y_len[:, None, None])).float()
+    path = maximum_path(value, mask)
+    mine = mas_oracle.maximum_path(value.numpy(), mask.numpy())
+    print("  mas oracle vs ref equal:", np.array_equal(mine, path.numpy()))
+    assert np.array_equal(mine, path.numpy())
+    save("mas", value=value, mask=mask, path=path, x_len=x_len, y_len=y_len)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     only = set(sys.argv[1:])
     for name, fn in [("stft", gen_stft), ("mel", gen_mel), ("vq", gen_vq), ("vq_forward", gen_vq_forward),
                      ("block", gen_block), ("losses", gen_losses), ("model", gen_model),
-                     ("model_train", gen_model_train_krand), ("ema", gen_ema)]:
+                     ("model_train", gen_model_train_krand), ("ema", gen_ema), ("mas", gen_mas)]:
         if only and name not in only:
             continue
         print(f"[{name}]")

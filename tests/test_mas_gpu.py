@@ -1,0 +1,35 @@
+"""Monotonic alignment search on the device (smt_maximum_path) against the reference's golden path and the
+numpy oracle: the 0/1 alignment must be identical."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mas_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_maximum_path_matches_reference_golden(golden):
+    from models.glow_tts.submodules import maximum_path
+    g = golden("mas")
+    value, mask = torch.from_numpy(g["value"]).cuda(), torch.from_numpy(g["mask"]).cuda()
+    path = maximum_path(value, mask)
+    assert path.dtype == value.dtype and path.device == value.device
+    assert np.array_equal(path.cpu().numpy(), g["path"])
+
+
+@pytest.mark.parametrize("b,t_x,t_y,seed", [(32, 200, 870, 0), (3, 300, 301, 1), (2, 1, 7, 2), (5, 64, 64, 3), (2, 513, 600, 4)])
+def test_maximum_path_matches_numpy_oracle(b, t_x, t_y, seed):
+    """LJSpeech-like sizes (<= 200 tokens x 870 mel frames per item), more than 256 rows (several rows per thread), one
+    token, square."""
+    from models.glow_tts.submodules import maximum_path
+    g = torch.Generator().manual_seed(seed)
+    value = torch.randn(b, t_x, t_y, generator=g) * 2.0
+    x_len = torch.randint(1, t_x + 1, (b,), generator=g); x_len[0] = t_x
+    y_len = torch.maximum(torch.randint(1, t_y + 1, (b,), generator=g), x_len.clamp(max=t_y)); y_len[0] = t_y
+    mask = ((torch.arange(t_x)[None, :, None] < x_len[:, None, None]) &
+            (torch.arange(t_y)[None, None, :] < y_len[:, None, None])).float()
+    ref = mas_oracle.maximum_path(value.numpy(), mask.numpy())
+    got = maximum_path(value.cuda(), mask.cuda()).cpu().numpy()
+    assert np.array_equal(got, ref)
+    assert got[0].sum() == t_y                                     # every frame of the full item is aligned

@@ -218,3 +218,16 @@ def test_counter_dropout_statistics():
     keep2 = orc.dropout_keep_ntc(seed=3, site=6, b=2, t=1000, c=64, p=0.1)
     assert 0.75 < (keep == keep2).mean() < 0.9  # independent sites: 0.81 + 0.01
     assert len(set(orc.dropout_site_ids(orc.VQVAEConfig()).values())) == 112
+
+
+def test_mas_oracle_matches_reference_golden(golden):
+    """oracle/mas_oracle.py against the path captured from the reference's maximum_path (submodules.py:28-67)."""
+    from oracle import mas_oracle
+    g = golden("mas")
+    path = mas_oracle.maximum_path(g["value"], g["mask"])
+    assert np.array_equal(path, g["path"])
+    # a monotonic alignment: on the regular items every unmasked frame is assigned to exactly one token, tokens ascend
+    for i in (0, 1):
+        xl, yl = int(g["x_len"][i]), int(g["y_len"][i])
+        p = path[i, :xl, :yl]
+        assert (p.sum(0) == 1).all() and (np.diff(p.argmax(0)) >= 0).all() and (np.diff(p.argmax(0)) <= 1).all()

@@ -290,6 +290,13 @@ int smt_stft_loss_fwd(const float* y, const float* yh, const int* lens, const fl
 int smt_stft_loss_bwd(const float* y, const float* yh, const int* lens, const float* window, const float* twiddle,
                       const float* coef, float* dyh, int batch, int t, int n_fft, int hop, smt_stream_t stream);
 
+/* STFT.inverse (datasets/transforms.py:125-156): magnitude, phase [batch, n_fft/2+1, frames] ->
+ * out [batch, (frames - 1) * hop + n_fft - 2 * ((n_fft - hop) / 2)]: inverse real FFT per frame, synthesis window,
+ * overlap-add, division by the window sum-square where it exceeds float tiny, pad_amount trimmed on both sides.
+ * window / twiddle as for smt_stft_magnitude. */
+int smt_stft_inverse(const float* magnitude, const float* phase, const float* window, const float* twiddle, float* out,
+                     int batch, int n_fft, int hop, int frames, smt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,40 @@ def sequence_mask(length: Tensor, max_length: Optional[int] = None) -> Tensor:
     return pos[None, :] < length[:, None]
 
 
+def window_sumsquare(n_fft: int, win_length: int, hop: int, n_frames: int) -> np.ndarray:
+    """librosa.filters.window_sumsquare(window="hann", n_frames, hop_length, win_length, n_fft, norm=None), restated from
+    its documented algorithm (librosa is absent offline -- parity unpinned for this helper): the squared periodic Hann
+    window, centre-padded to n_fft, summed at every frame offset; length n_fft + hop * (n_frames - 1)."""
+    win_sq = stft_window(n_fft, win_length).astype(np.float32) ** 2
+    n = n_fft + hop * (n_frames - 1)
+    x = np.zeros(n, dtype=np.float32)
+    for i in range(n_frames):
+        sample = i * hop
+        x[sample:min(n, sample + n_fft)] += win_sq[:max(0, min(n_fft, n - sample))]
+    return x
+
+
+def stft_inverse(magnitude: Tensor, phase: Tensor, n_fft: int, hop: int, win_length: int, sumsquare=None) -> Tensor:
+    """STFT.inverse (transforms.py:125-156) with the inverse basis of STFT.__init__ (:86-105), same operations in the same
+    order: recombine, conv_transpose1d with the windowed pseudo-inverse basis, divide by the window sum-square where it
+    exceeds float tiny, times n_fft / hop, trim pad_amount on both sides."""
+    scale = n_fft / hop
+    pad = (n_fft - hop) // 2
+    fourier = np.fft.fft(np.eye(n_fft))
+    cutoff = n_fft // 2 + 1
+    basis = np.vstack([np.real(fourier[:cutoff]), np.imag(fourier[:cutoff])])
+    inv = torch.tensor(np.linalg.pinv(scale * basis).T[:, None, :], dtype=torch.float32)
+    inv = inv * torch.from_numpy(np.asarray(stft_window(n_fft, win_length))).float()
+    rec = torch.cat([magnitude * torch.cos(phase), magnitude * torch.sin(phase)], dim=1)
+    out = F.conv_transpose1d(rec, inv, stride=hop, padding=0)
+    wss = (sumsquare or window_sumsquare)(n_fft, win_length, hop, magnitude.size(-1))
+    nz = torch.from_numpy(np.where(wss > np.finfo(np.float32).tiny)[0])
+    out[:, :, nz] /= torch.from_numpy(wss)[nz]
+    out *= scale
+    out = out[:, :, pad:]
+    return out[:, :, :-pad]
+
+
 # ---------------------------------------------------------------------------
 # STFT / mel front end  (datasets/transforms.py)
 # ---------------------------------------------------------------------------

@@ -12,6 +12,8 @@
 //     by Hermitian symmetry, then emits per-frame partial sums of the linear and log terms;
 //   * backward recomputes the spectra, forms dL/dYh on the one-sided spectrum, applies the adjoint
 //     transform (a complex FFT with conjugate twiddles), windows it and overlap-adds into dyh.
+#include <algorithm>
+
 #include "smt_common.h"
 
 namespace smt {
@@ -259,6 +261,63 @@ using namespace smt;
       return 1;                                                             \
   }
 
+// ------------------------------------------------------------- inverse ------
+// STFT.inverse (datasets/transforms.py:125-156).  The reference multiplies [mag cos(phi); mag sin(phi)] by the
+// pseudo-inverse of its stacked real DFT basis (conv_transpose1d, stride = hop): the rows of that basis are orthogonal, so
+// the pseudo-inverse IS the inverse real FFT, x[n] = (1/N)(X_0 + (-1)^n X_{N/2}) + (2/N) sum_{0<k<N/2} Re(X_k e^{+2 pi i k n/N})
+// (the imaginary parts of bins 0 and N/2 meet zero rows and drop out), times 1/scale; then the synthesis window, the
+// overlap-add, the division by the window sum-square (librosa.filters.window_sumsquare) where it is above float tiny,
+// the factor scale = n_fft / hop (cancelling the 1/scale), and the trim of pad_amount samples on both sides.
+// One workgroup per frame: one-sided weighted spectrum -> complex in-LDS FFT with conjugate twiddles -> windowed real
+// part added into the trimmed output (f32 atomics); a second elementwise kernel divides by the window sum-square.
+template <int N>
+__global__ __launch_bounds__(256) void stft_inverse_kernel(const float* __restrict__ mag, const float* __restrict__ phase,
+                                                           const float* __restrict__ window, const cplx* __restrict__ tw,
+                                                           float* __restrict__ out, int hop, int pad, int frames, int t_out) {
+  __shared__ cplx buf[2][N];
+  const int f = blockIdx.x, b = blockIdx.y;
+  const size_t bins = N / 2 + 1;
+  const float* mb = mag + (size_t)b * bins * frames;
+  const float* pb = phase + (size_t)b * bins * frames;
+  for (int k = threadIdx.x; k < N; k += 256) {
+    cplx g = {0.f, 0.f};
+    if (k <= N / 2) {
+      const float m = mb[(size_t)k * frames + f], ph = pb[(size_t)k * frames + f];
+      float s, c;
+      sincosf(ph, &s, &c);
+      const bool edge = (k == 0) || (k == N / 2);
+      const float wgt = edge ? 1.f / (float)N : 2.f / (float)N;
+      g = {wgt * m * c, edge ? 0.f : wgt * m * s};
+    }
+    buf[0][k] = g;
+  }
+  __syncthreads();
+  const cplx* R = fft_lds<N>(buf[0], buf[1], tw, true);     // R[n].x = sum_k Re(G_k e^{+2 pi i k n / N})
+  float* ob = out + (size_t)b * t_out;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float w = window[n];
+    const int i = f * hop + n - pad;                         // position in the trimmed signal
+    if (w != 0.f && i >= 0 && i < t_out) atomicAdd(ob + i, w * R[n].x);
+  }
+}
+
+__global__ __launch_bounds__(256) void stft_inverse_norm_kernel(const float* __restrict__ window, float* __restrict__ out,
+                                                                int n_fft, int hop, int pad, int frames, int t_out, int batch) {
+  const long long total = (long long)batch * t_out;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int i = (int)(e % t_out) + pad;                    // position in the untrimmed overlap-add
+    // window sum-square at i: frames f with 0 <= i - f hop < n_fft
+    const int f_hi = min(frames - 1, i / hop);
+    const int f_lo = max(0, (i - n_fft + hop) / hop);
+    float wss = 0.f;
+    for (int f = f_lo; f <= f_hi; ++f) {
+      const int n = i - f * hop;
+      if (n >= 0 && n < n_fft) { const float w = window[n]; wss += w * w; }
+    }
+    if (wss > 1.17549435e-38f) out[e] = out[e] / wss;        // librosa.util.tiny(float32)
+  }
+}
+
 static int stft_frames(int T, int n_fft, int hop) { return (T + 2 * ((n_fft - hop) / 2) - n_fft) / hop + 1; }
 
 extern "C" int smt_stft_num_frames(int t, int n_fft, int hop) { return stft_frames(t, n_fft, hop); }
@@ -322,5 +381,24 @@ extern "C" int smt_melspec(const float* x, const float* window, const float* twi
   SMT_FFT_DISPATCH(n_fft, (melspec_kernel<N><<<grid, 256, 0, stream>>>(x, window, (const cplx*)twiddle, mel_basis, band,
                                                                      mel, t, hop, pad, frames, n_mels)));
   SMT_CHECK_LAUNCH("melspec");
+  return 0;
+}
+
+extern "C" int smt_stft_inverse(const float* magnitude, const float* phase, const float* window, const float* twiddle,
+                                float* out, int batch, int n_fft, int hop, int frames, smt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SMT_CHECK_ARG(magnitude && phase && window && twiddle && out, "smt_stft_inverse: null pointer");
+  const int pad = (n_fft - hop) / 2;
+  const int t_out = (frames - 1) * hop + n_fft - 2 * pad;
+  if (batch <= 0 || frames <= 0 || t_out <= 0) return 0;
+  (void)hipMemsetAsync(out, 0, (size_t)batch * t_out * sizeof(float), stream);
+  dim3 grid(frames, batch);
+  SMT_FFT_DISPATCH(n_fft, (stft_inverse_kernel<N><<<grid, 256, 0, stream>>>(magnitude, phase, window, (const cplx*)twiddle, out,
+                                                                          hop, pad, frames, t_out)));
+  SMT_CHECK_LAUNCH("stft_inverse");
+  const long long total = (long long)batch * t_out;
+  stft_inverse_norm_kernel<<<(unsigned)std::min<long long>(2048, (total + 255) / 256), 256, 0, stream>>>(window, out, n_fft, hop,
+                                                                                                   pad, frames, t_out, batch);
+  SMT_CHECK_LAUNCH("stft_inverse_norm");
   return 0;
 }

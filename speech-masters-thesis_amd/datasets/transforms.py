@@ -57,6 +57,11 @@ class STFT(nn.Module):
         b, t = input_data.shape[0], input_data.shape[-1]
         return spectral.stft_magnitude(input_data.reshape(b, t), self.n_fft, self.hop_length, self.win_length)
 
+    def inverse(self, magnitude, phase):
+        """magnitude, phase [B, n_fft/2 + 1, frames] -> [B, 1, T'] (transforms.py:125-156): inverse FFT per frame, synthesis
+        window, overlap-add, window-sum-square normalisation, pad_amount trimmed on both sides -- one HIP kernel pair."""
+        return spectral.stft_inverse(magnitude, phase, self.n_fft, self.hop_length, self.win_length)
+
 
 class MelSpectrogram(nn.Module):
     def __init__(self, n_fft=1024, hop_length=256, win_length=None, n_mels=80, sample_rate=22050, f_min=0.0,

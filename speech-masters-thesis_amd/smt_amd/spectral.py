@@ -48,6 +48,21 @@ def stft_magnitude(x, n_fft, hop, win_length):
 
 
 @torch.no_grad()
+def stft_inverse(magnitude, phase, n_fft, hop, win_length):
+    """magnitude, phase [B, n_fft/2+1, frames] -> audio [B, 1, T'] (STFT.inverse, transforms.py:125-156)."""
+    magnitude, phase = magnitude.contiguous().float(), phase.contiguous().float()
+    b, bins, frames = magnitude.shape
+    assert bins == n_fft // 2 + 1 and phase.shape == magnitude.shape
+    window, tw = _get_tables(n_fft, win_length, magnitude.device)
+    pad = (n_fft - hop) // 2
+    out = torch.empty(b, (frames - 1) * hop + n_fft - 2 * pad, dtype=torch.float32, device=magnitude.device)
+    with profiler.region("stft_inverse", nbytes=2 * magnitude.numel() * 4 + out.numel() * 4, bound="hbm"):
+        N.check(N.lib().smt_stft_inverse(N.ptr(magnitude), N.ptr(phase), N.ptr(window), N.ptr(tw), N.ptr(out), b, n_fft, hop,
+                                         frames, N.stream_ptr()), "smt_stft_inverse")
+    return out.unsqueeze(1)
+
+
+@torch.no_grad()
 def log_mel(x, mel_basis, band, n_fft, hop, win_length):
     """x [B, T] -> log-mel [B, n_mels, frames] in one kernel (5.25 B/sample algorithmic)."""
     x = x.contiguous().float()

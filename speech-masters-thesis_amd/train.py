@@ -21,7 +21,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))  # ahead of any p
 from utils import config as cfglib  # noqa: E402
 from utils.commons import get_dataloaders, get_model, get_optimizer, setup_logdir, to_device  # noqa: E402
 from utils.train_utils import (ScalarWriter, accumulate_stats, barrier, log_stats,  # noqa: E402
-                               print_top_level_summary, restore_extra_train_state, save_checkpoint, seed_all_rng)
+                               print_top_level_summary, restore_extra_train_state, save_audio_and_computed_spect,
+                               save_checkpoint, seed_all_rng)
 
 logging.basicConfig(level=logging.INFO, format="%(asctime)s %(name)s %(levelname)s: %(message)s")
 logger = logging.getLogger("train")
@@ -102,11 +103,20 @@ def val_epoch(*, epoch, config, model, ema, val_dataloader, writer, device):
     losses, metrics = defaultdict(float), defaultdict(float)
     model.eval()
     ema.swap()
+    ys, yhs = [], []
     for batch in val_dataloader:
         loss_dict, metrics_dict = model.supervised_step(to_device(batch, device))
         accumulate_stats(len(val_dataloader), loss_dict, metrics_dict, losses, metrics)
+        if "y" in loss_dict and "yh" in loss_dict and len(ys) < 4:          # train.py:274-275
+            ys += list(loss_dict["y"][:4 - len(ys)]); yhs += list(loss_dict["yh"][:4 - len(yhs)])
     ema.swap()
     log_stats(epoch, writer, losses, metrics, prefix="val")
+    from models.base import WaveformReconstructionModel
+    if isinstance(model, WaveformReconstructionModel) and ys:               # train.py:296-299
+        n = min(len(ys), len(yhs))
+        t = min(min(v.shape[-1] for v in ys[:n]), min(v.shape[-1] for v in yhs[:n]))
+        save_audio_and_computed_spect(config, epoch, writer, torch.stack([v[:t] for v in ys[:n]]),
+                                      torch.stack([v[:t] for v in yhs[:n]]), n=n)
     return {**losses, **metrics}
 
 

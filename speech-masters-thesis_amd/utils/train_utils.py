@@ -127,6 +127,76 @@ def restore_extra_train_state(model, extra):
         model._drop_seed = int(extra["drop_seed"])
 
 
+def write_wav(path, samples, sample_rate):
+    """16-bit mono PCM through the stdlib (the reference uses soundfile, train_utils.py:267-277)."""
+    import wave
+    pcm = (np.clip(np.asarray(samples, dtype=np.float64), -1.0, 1.0) * 32767.0).astype("<i2")
+    with wave.open(path, "wb") as f:
+        f.setnchannels(1); f.setsampwidth(2); f.setframerate(int(sample_rate))
+        f.writeframes(pcm.tobytes())
+
+
+def write_png_gray(path, image):
+    """8-bit greyscale PNG with zlib + struct only (the reference draws its grids with matplotlib + PIL)."""
+    import struct
+    import zlib
+    img = np.ascontiguousarray(image, dtype=np.uint8)
+    h, w = img.shape
+    raw = b"".join(b"\x00" + img[r].tobytes() for r in range(h))
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+def spects_to_grid(ys, yhs, n=4):
+    """Pairs of spectrograms [n_mels, frames] -> one uint8 image: row i = ground truth | prediction, low frequencies at
+    the bottom, a common grey scale per pair (train_utils.py:174-195 without matplotlib)."""
+    rows = []
+    for i in range(min(n, len(ys))):
+        a, b = np.asarray(ys[i], dtype=np.float32), np.asarray(yhs[i], dtype=np.float32)
+        frames = max(a.shape[1], b.shape[1])
+        lo, hi = min(a.min(), b.min()), max(a.max(), b.max())
+        pair = np.zeros((a.shape[0], 2 * frames + 4), dtype=np.uint8)
+        for off, m in ((0, a), (frames + 4, b)):
+            pair[:, off:off + m.shape[1]] = np.clip(255.0 * (m[::-1] - lo) / max(hi - lo, 1e-12), 0, 255).astype(np.uint8)
+        rows += [pair, np.zeros((4, pair.shape[1]), dtype=np.uint8)]
+    width = max(r.shape[1] for r in rows)
+    return np.concatenate([np.pad(r, ((0, 0), (0, width - r.shape[1]))) for r in rows], axis=0)
+
+
+@torch.no_grad()
+def save_audio_and_computed_spect(config, global_step, writer, audio, audio_pred, n=4):
+    """Validation artefacts of a waveform model (reference train_utils.py:249-304): the first clip and its reconstruction as
+    wav files, and a grid of the log-mel spectrograms of the first `n` pairs.  The mel front end is this build's HIP
+    kernel (the reference's own MelSpectrogram, log of the mel-filtered MAGNITUDE) instead of librosa's power-dB
+    spectrogram, which is not available offline; the image is a greyscale PNG."""
+    from datasets.transforms import MelSpectrogram
+    ds, log_dir = config.dataset, config.train.log_dir
+    for sub in ("audio", "spect"):
+        os.makedirs(os.path.join(log_dir, sub), exist_ok=True)
+    audio, audio_pred = audio.detach().float().clamp(-1, 1), audio_pred.detach().float().clamp(-1, 1)
+    write_wav(os.path.join(log_dir, "audio", f"val_audio_{global_step}_gt.wav"), audio[0].cpu().numpy(), ds.sample_rate)
+    write_wav(os.path.join(log_dir, "audio", f"val_audio_{global_step}_pred.wav"), audio_pred[0].cpu().numpy(), ds.sample_rate)
+    k = min(n, audio.shape[0])
+    device = audio.device if audio.is_cuda else torch.device("cuda")
+    mel = MelSpectrogram(sample_rate=ds.sample_rate, n_fft=ds.n_fft, win_length=ds.win_length, hop_length=ds.hop_length,
+                         n_mels=ds.n_mels, f_min=0.0, f_max=8000.0).to(device)
+    spect, spect_pred = mel(audio[:k].to(device)).cpu().numpy(), mel(audio_pred[:k].to(device)).cpu().numpy()
+    grid = spects_to_grid(spect, spect_pred, n=k)
+    path = os.path.join(log_dir, "spect", f"val_spect_{global_step}.png")
+    write_png_gray(path, grid)
+    tb = getattr(writer, "_tb", None)
+    if tb is not None:
+        tb.add_image("mel/val", grid, global_step, dataformats="HW")
+        tb.add_audio("audio/val_gt", audio[0].cpu(), global_step=global_step, sample_rate=ds.sample_rate)
+        tb.add_audio("audio/val_pred", audio_pred[0].cpu(), global_step=global_step, sample_rate=ds.sample_rate)
+    return path
+
+
 def print_top_level_summary(model):
     rows = []
     for name, module in model.named_children():

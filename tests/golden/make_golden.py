@@ -34,6 +34,7 @@ sys.dont_write_bytecode = True
 import logging.config  # noqa: E402  (models/ema.py uses logging.config after a bare import)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
 import yaml  # noqa: E402
 
 from oracle import vqvae_oracle as orc  # noqa: E402
@@ -448,6 +449,37 @@ def gen_ema():
     save("param_ema", **out)
 
 
+def gen_stft_inverse():
+    """STFT.inverse (datasets/transforms.py:125-156) run by the reference itself.  It calls librosa.filters.window_sumsquare
+    (librosa is absent): that ONE helper is supplied by the oracle's restatement of its documented algorithm -- the
+    fixture pins the reference's inverse basis, conv_transpose1d, normalisation rule, scaling and trimming; the sum-square
+    helper itself stays parity-unpinned (stated in DESIGN.md)."""
+    librosa.filters.window_sumsquare = lambda window, n_frames, hop_length, win_length, n_fft, dtype=np.float32: \
+        orc.window_sumsquare(n_fft, win_length, hop_length, n_frames)
+    g = torch.Generator().manual_seed(111)
+    out = {}
+    for tag, (n_fft, hop, win) in {"a": (1024, 256, 1024), "b": (512, 50, 240), "c": (2048, 240, 1200)}.items():
+        stft = STFT(n_fft=n_fft, hop_length=hop, win_length=win, window="hann")
+        x = synth(1, 3 * n_fft + 1000, 7 + n_fft)
+        frames = stft(x).shape[-1]
+        # a consistent (magnitude, phase) pair of the signal itself, from the reference's own forward bases
+        pad = (n_fft - hop) // 2
+        xp = F.pad(x.unsqueeze(1), (pad, pad), mode="reflect")
+        ft = F.conv1d(xp, stft.forward_basis, stride=hop)
+        cutoff = n_fft // 2 + 1
+        re, im = ft[:, :cutoff], ft[:, cutoff:]
+        mag, phase = torch.sqrt(re ** 2 + im ** 2), torch.atan2(im, re)
+        assert mag.shape[-1] == frames
+        y = stft.inverse(mag, phase)
+        mine = orc.stft_inverse(mag, phase, n_fft, hop, win)
+        print(f"  stft_inverse {tag}: oracle vs ref {float((mine - y).abs().max()):.2e}; round trip vs x "
+              f"{float((y[:, 0, n_fft:-n_fft] - x[:, n_fft:y.shape[-1] - n_fft]).abs().max()):.2e}")
+        assert torch.allclose(mine, y, atol=1e-6)
+        out.update({f"{tag}_mag": mag, f"{tag}_phase": phase, f"{tag}_y": y, f"{tag}_x": x,
+                    f"{tag}_cfg": np.array([n_fft, hop, win])})
+    save("stft_inverse", **out)
+
+
 def gen_mas():
     """models/glow_tts/submodules.py:28-67 `maximum_path`, the reference's own function.  It spells numpy's bool as
     `np.bool`, an alias numpy >= 1.24 no longer has: restored in memory for the call (same meaning, nothing else touched)."""
@@ -474,7 +506,7 @@ if __name__ == "__main__":
     only = set(sys.argv[1:])
     for name, fn in [("stft", gen_stft), ("mel", gen_mel), ("vq", gen_vq), ("vq_forward", gen_vq_forward),
                      ("block", gen_block), ("losses", gen_losses), ("model", gen_model),
-                     ("model_train", gen_model_train_krand), ("ema", gen_ema), ("mas", gen_mas)]:
+                     ("model_train", gen_model_train_krand), ("ema", gen_ema), ("mas", gen_mas), ("stft_inverse", gen_stft_inverse)]:
         if only and name not in only:
             continue
         print(f"[{name}]")

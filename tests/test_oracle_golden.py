@@ -231,3 +231,15 @@ def test_mas_oracle_matches_reference_golden(golden):
         xl, yl = int(g["x_len"][i]), int(g["y_len"][i])
         p = path[i, :xl, :yl]
         assert (p.sum(0) == 1).all() and (np.diff(p.argmax(0)) >= 0).all() and (np.diff(p.argmax(0)) <= 1).all()
+
+
+def test_stft_inverse_oracle_matches_reference_golden(golden):
+    """oracle.stft_inverse against STFT.inverse of the reference (transforms.py:125-156; window_sumsquare restated, see
+    tests/golden/make_golden.py: stft_inverse), and the round trip back to the signal away from the edges."""
+    g = golden("stft_inverse")
+    for tag in "abc":
+        n_fft, hop, win = (int(v) for v in g[f"{tag}_cfg"])
+        y = orc.stft_inverse(torch.from_numpy(g[f"{tag}_mag"]), torch.from_numpy(g[f"{tag}_phase"]), n_fft, hop, win)
+        assert torch.allclose(y, torch.from_numpy(g[f"{tag}_y"]), atol=1e-6)
+        x = torch.from_numpy(g[f"{tag}_x"])
+        assert (y[:, 0, n_fft:-n_fft] - x[:, n_fft:y.shape[-1] - n_fft]).abs().max() < 5e-6

@@ -105,3 +105,34 @@ def test_recon_loss_kernel_matches_torch_topk(b, t, topk, lens):
     assert np.isclose(loss.item(), ref.item(), rtol=2e-6)
     # ties only occur among masked zeros (gradient 0 either way), so the gradient is comparable element-wise
     assert torch.allclose(gr, gref, rtol=1e-5, atol=1e-9)
+
+
+def test_stft_inverse_matches_reference_golden(golden):
+    """smt_stft_inverse behind STFT.inverse against the reference's own inverse (fixture), three parameter sets; fp32,
+    1e-5 of the signal scale (FFT vs pseudo-inverse matmul)."""
+    from datasets.transforms import STFT
+    g = golden("stft_inverse")
+    for tag in "abc":
+        n_fft, hop, win = (int(v) for v in g[f"{tag}_cfg"])
+        stft = STFT(n_fft=n_fft, hop_length=hop, win_length=win, window="hann")
+        y = stft.inverse(T(g[f"{tag}_mag"]).cuda(), T(g[f"{tag}_phase"]).cuda())
+        ref = T(g[f"{tag}_y"])
+        assert y.shape == ref.shape
+        assert torch.allclose(y.cpu(), ref, atol=1e-5), (tag, float((y.cpu() - ref).abs().max()))
+
+
+def test_stft_inverse_round_trip_at_clip_length():
+    """Property at LJSpeech size: analysis (complex STFT with the reference's framing, computed here with torch.stft on the
+    manually reflect-padded signal) followed by the inverse kernel returns the clip, away from the first / last window."""
+    from smt_amd import spectral
+    n_fft, hop, win = 1024, 256, 1024
+    b, t = 4, 145408
+    x = orc.synthetic_clip_batch(b, t, 3)[:, 0].cuda()
+    pad = (n_fft - hop) // 2
+    xp = torch.nn.functional.pad(x.unsqueeze(1), (pad, pad), mode="reflect")[:, 0]
+    spec = torch.stft(xp, n_fft, hop_length=hop, win_length=win, window=torch.hann_window(win, periodic=True, device="cuda"),
+                      center=False, return_complex=True)
+    y = spectral.stft_inverse(spec.abs(), torch.angle(spec), n_fft, hop, win)[:, 0]
+    assert y.shape[-1] == (spec.shape[-1] - 1) * hop + n_fft - 2 * pad
+    n = min(y.shape[-1], t)
+    assert (y[:, n_fft:n - n_fft] - x[:, n_fft:n - n_fft]).abs().max() < 2e-5

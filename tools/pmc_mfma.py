@@ -21,6 +21,7 @@ GROUPS = [
     ("conv_gemm_dma", ["conv_gemm_dma_kernel"]),
     ("conv_gemm", ["conv_gemm_kernel"]),
     ("conv1x1_fold", ["conv1x1_fold_kernel"]),
+    ("conv_k3gate", ["conv_k3gate_kernel"]),
     ("conv1x1_bwd", ["conv1x1_bwd_kernel"]),
     ("conv_k1act", ["conv_k1act_kernel"]),
     ("conv_k1_bwd", ["conv_k1_bwd_kernel"]),

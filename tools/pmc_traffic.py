@@ -14,6 +14,7 @@ GROUPS = [  # (key, substrings of the kernel name)
     ("conv_gemm_dma_kernel", ["conv_gemm_dma_kernel"]),
     ("conv1x1_dma_kernel", ["conv1x1_dma_kernel"]),
     ("conv1x1_fold_kernel", ["conv1x1_fold_kernel"]),
+    ("conv_k3gate_kernel", ["conv_k3gate_kernel"]),
     ("conv1x1_bwd_kernel", ["conv1x1_bwd_kernel"]),
     ("conv_k1act_kernel", ["conv_k1act_kernel"]),
     ("conv_k1_bwd_kernel", ["conv_k1_bwd_kernel"]),

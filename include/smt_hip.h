@@ -221,6 +221,20 @@ int smt_conv_k1_bwd(const void* dh, int64_t bs_dh, int ld_dh, const void* x, int
                     int64_t stride_out, int64_t stride_in, float* dbias, void* workspace, size_t workspace_bytes,
                     smt_stream_t stream);
 
+/* The k = 4 / stride 2 / padding 1 resampling convolutions at width 64 (bf16; conv.py:61-78,111-137) as HBM-streaming kernels:
+ *   smt_convt4s2: y[b, 2m]   = bias + W1 x[b, m] + W3 x[b, m-1]        x [B, t_in, 64] -> y [B, 2 t_in, c_out], c_out in {64,128}
+ *                 y[b, 2m+1] = bias + W2 x[b, m] + W0 x[b, m+1]        (MaskedConvTranspose1d forward; data gradient of conv4s2)
+ *   smt_conv4s2 : y[b, t]    = bias + sum_j Wj x[b, 2t + j - 1]        x [B, t_in, c_in], c_in in {64,128} -> y [B, t_in/2, 64]
+ *                                                                      (MaskedConv1d forward; data gradient of convt4s2)
+ * w_packed = smt_pack_weight layout [tap][c_out][c_in], swizzle 0; bias fp32 or NULL; x rows >= lens_in[b] read as zero,
+ * y rows >= lens_out[b] are written as zero (either may be NULL); zero_page >= 256 zero bytes. */
+int smt_convt4s2(const void* x, int64_t bs_x, int ld_x, const void* w_packed, const float* bias, void* y, int64_t bs_y,
+                 int ld_y, const int* lens_in, const int* lens_out, int batch, int t_in, int c_out, const void* zero_page,
+                 smt_stream_t stream);
+int smt_conv4s2(const void* x, int64_t bs_x, int ld_x, const void* w_packed, const float* bias, void* y, int64_t bs_y,
+                int ld_y, const int* lens_in, const int* lens_out, int batch, int t_in, int c_in, const void* zero_page,
+                smt_stream_t stream);
+
 /* K3 of all four branches of a GatedHiFiBlock + the tanh * softmax gate in one pass (bf16, width 64; resnet.py:224-237):
  *   z[b,t,128 d + c] = b3[d][c] + sum_i W3_d[c][i] u2[b,t,128 d + i]  +  b1[d][c] + sum_j W1_d[c][j] x[b,t,j]     d = 0..3
  *   g[b,t,c]         = sum_d tanh(z[.., 128 d + c]) * softmax_d(z[.., 128 d + 64 + c])                             c < 64

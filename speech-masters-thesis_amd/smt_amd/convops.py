@@ -438,6 +438,27 @@ def _pack_bwd(weight, dtype, swizzle=False):
     return _pack(weight, dtype, c_in, c_out, k, c_in * k, 1, [k - 1 - j for j in range(k)], swizzle)
 
 
+_RESAMPLE = not bool(int(__import__("os").environ.get("SMT_NO_RESAMPLE", "0")))   # A/B switch for tests and profiles
+
+
+def _resample_ok(x_dtype, k, stride, padding, dilation, c_narrow, c_wide):
+    """k = 4 / stride 2 / padding 1 at width 64 (the narrow side) and 64 or 128 on the other: the streaming kernels."""
+    return (_RESAMPLE and x_dtype == torch.bfloat16 and k == 4 and stride == 2 and padding == 1 and dilation == 1 and
+            c_narrow == 64 and c_wide in (64, 128))
+
+
+def _resample(kind, name, x, wp, bias, y, lens_in, lens_out, c_other):
+    """kind 'conv' = smt_conv4s2 (c_other = input channels), 'convt' = smt_convt4s2 (c_other = output channels)."""
+    (px, bsx, ldx_), (py, bsy, ldy) = _geom(x), _geom(y)
+    b, t_in = x.shape[0], x.shape[1]
+    nbytes = (x.numel() + y.numel()) * 2.0
+    flops = 2.0 * b * (t_in // 2 if kind == "conv" else t_in * 2) * (4 if kind == "conv" else 2) * 64 * c_other
+    fn = N.lib().smt_conv4s2 if kind == "conv" else N.lib().smt_convt4s2
+    with profiler.region(("conv4s2:" if kind == "conv" else "convt4s2:") + name, nbytes=nbytes, flops=flops, bound="hbm", dtype="bf16"):
+        N.check(fn(px, bsx, ldx_, _p(wp), _p(bias), py, bsy, ldy, _p(lens_in), _p(lens_out), b, t_in, c_other,
+                   _p(_zero_page(x.device)), N.stream_ptr()), "smt_conv4s2" if kind == "conv" else "smt_convt4s2")
+
+
 class _Conv1d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, lens, stride, padding, dilation):
@@ -447,11 +468,14 @@ class _Conv1d(torch.autograd.Function):
         y = torch.empty(b, t_out, c_out, dtype=x.dtype, device=x.device)
         lens32 = _i32(lens)
         wp = _pack_fwd(weight, x.dtype)
-        d = _base_desc(x, y, lens32, c_in, c_out, k, stride, dilation, padding, t_out)
-        d.w, d.bias = _p(wp), _p(bias)
-        if residual is not None:
-            d.res, d.bs_res, d.ld_res = _geom(residual)
-        _launch(d, "conv_fwd", _conv_flops(d), _conv_bytes(d, x.element_size()))
+        if residual is None and t_in % 2 == 0 and _resample_ok(x.dtype, k, stride, padding, dilation, c_out, c_in):
+            _resample("conv", "fwd", x, wp, bias, y, lens32, None, c_in)
+        else:
+            d = _base_desc(x, y, lens32, c_in, c_out, k, stride, dilation, padding, t_out)
+            d.w, d.bias = _p(wp), _p(bias)
+            if residual is not None:
+                d.res, d.bs_res, d.ld_res = _geom(residual)
+            _launch(d, "conv_fwd", _conv_flops(d), _conv_bytes(d, x.element_size()))
         ctx.save_for_backward(x, weight, lens32 if lens32 is not None else torch.empty(0))
         ctx.cfg = (stride, padding, dilation, lens is not None, residual is not None, bias is not None)
         return y
@@ -473,6 +497,10 @@ class _Conv1d(torch.autograd.Function):
                 d = _dgrad_stride1(dy, _pack_bwd(weight, x.dtype), dx, k, dilation, padding)
                 d.lens_out = _p(lens32)
                 _launch(d, "conv_dgrad", _conv_flops(d), _conv_bytes(d, x.element_size()))
+            elif t_in == 2 * t_out and _resample_ok(x.dtype, k, stride, padding, dilation, c_out, c_in):
+                # dx[2m + ph] = two taps of W^T on dy: the transposed streaming kernel, both phases from one read of dy
+                wt = _pack(weight, x.dtype, c_in, c_out, k, c_in * k, 1, list(range(k)))
+                _resample("convt", "dgrad", dy, wt, None, dx, None, lens32, c_in)
             else:
                 for ph, (taps, pad_eff) in enumerate(_phases(k, stride, padding)):
                     n_ph = (t_in - ph + stride - 1) // stride
@@ -507,7 +535,11 @@ class _ConvTranspose1d(torch.autograd.Function):
         t_y = (t_in - 1) * stride - 2 * padding + k
         y = torch.empty(b, t_y, c_out, dtype=x.dtype, device=x.device)
         lens32 = _i32(lens)
-        for ph, (taps, pad_eff) in enumerate(_phases(k, stride, padding)):
+        fast = _resample_ok(x.dtype, k, stride, padding, 1, c_in, c_out)
+        if fast:
+            _resample("convt", "fwd", x, _pack(weight, x.dtype, c_out, c_in, k, c_out * k, 1, list(range(k))), bias, y, lens32,
+                      None, c_out)
+        for ph, (taps, pad_eff) in enumerate(() if fast else _phases(k, stride, padding)):
             n_ph = (t_y - ph + stride - 1) // stride
             wp = _pack(weight, x.dtype, c_out, c_in, k, c_out * k, 1, taps)
             d = _base_desc(x, y, lens32, c_in, c_out, len(taps), 1, 1, pad_eff, n_ph, stride, ph)
@@ -532,10 +564,13 @@ class _ConvTranspose1d(torch.autograd.Function):
             # dx[m, ci] = sum_j sum_co dy[s*m + j - p, co] W[ci, co, j]: a strided convolution over dy
             dx = torch.empty(b, t_in, c_in, dtype=x.dtype, device=x.device)
             wb = _pack(weight, x.dtype, c_in, c_out, c_out * k, k, 1, list(range(k)))
-            d = _base_desc(dy, dx, None, c_out, c_in, k, stride, 1, padding, t_in)
-            d.w = _p(wb)
-            d.lens_out = _p(lens32)
-            _launch(d, "conv_dgrad", _conv_flops(d), _conv_bytes(d, x.element_size()))
+            if t_y == 2 * t_in and _resample_ok(x.dtype, k, stride, padding, 1, c_in, c_out):
+                _resample("conv", "dgrad", dy, wb, None, dx, None, lens32, c_out)
+            else:
+                d = _base_desc(dy, dx, None, c_out, c_in, k, stride, 1, padding, t_in)
+                d.w = _p(wb)
+                d.lens_out = _p(lens32)
+                _launch(d, "conv_dgrad", _conv_flops(d), _conv_bytes(d, x.element_size()))
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
             db = torch.zeros(c_out, dtype=torch.float32, device=x.device)

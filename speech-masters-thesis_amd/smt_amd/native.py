@@ -46,6 +46,8 @@ _SIGNATURES = {
     "smt_conv_k1_bwd_workspace_bytes": (c_size, [c_int, c_int]),
     "smt_conv_k1_bwd": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64,
                                 c_int, c_ptr, c_int, c_int, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_size, c_ptr]),
+    "smt_convt4s2": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr]),
+    "smt_conv4s2": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr]),
     "smt_conv_k3gate_fwd": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int,
                                     c_ptr, c_i64, c_int, c_ptr, c_int, c_int, c_ptr, c_ptr]),
     "smt_gate_mix_fwd": (c_int, [c_ptr, c_ptr, c_int, c_i64, c_int, c_int, c_int, c_int, c_ptr]),

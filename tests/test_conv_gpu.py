@@ -673,3 +673,41 @@ def test_full_size_properties_of_the_fused_backward_kernels():
     a, bq = gate(dout), gate(dout * 2)
     torch.cuda.synchronize()
     assert torch.equal(bq[0], a[0] * 2) and torch.equal(bq[1], a[1] * 2) and torch.equal(bq[2], a[2] * 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c_wide", [64, 128])
+def test_resampling_stream_kernels_match_the_generic_kernel(c_wide):
+    """smt_conv4s2 / smt_convt4s2 (k = 4, stride 2, padding 1, width 64) against the generic implicit-GEMM launches they
+    replace: forward and data gradient of the strided conv (c_wide -> 64) and of the transposed conv (64 -> c_wide),
+    ragged lens, a length that is not a multiple of the 128-row tile, bias, bit-identical outputs."""
+    from smt_amd import convops as C
+    from smt_amd import profiler
+    g = torch.Generator(device="cuda").manual_seed(c_wide)
+    b, t = 3, 2 * 1237
+    lens = torch.tensor([t, t - 501, 64], device="cuda", dtype=torch.int32)
+    x = torch.randn(b, t, c_wide, device="cuda", generator=g).to(torch.bfloat16)
+    w = torch.randn(64, c_wide, 4, device="cuda", generator=g) / (c_wide * 4) ** 0.5
+    bias = torch.randn(64, device="cuda", generator=g)
+    xt = torch.randn(b, t // 2, 64, device="cuda", generator=g).to(torch.bfloat16)
+    wt = torch.randn(64, c_wide, 4, device="cuda", generator=g) / 16
+    bt = torch.randn(c_wide, device="cuda", generator=g)
+    res = []
+    for fast in (True, False):
+        C._RESAMPLE = fast
+        try:
+            profiler.reset(); profiler.enable(True)
+            xa, wa, ba = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+            y = C.conv1d(xa, wa, ba, stride=2, padding=1, lens=lens)
+            y.backward(torch.ones_like(y) * 0.5 + y.detach() * 0.25)
+            xb, wb, bb = xt.clone().requires_grad_(True), wt.clone().requires_grad_(True), bt.clone().requires_grad_(True)
+            z = C.conv_transpose1d(xb, wb, bb, stride=2, padding=1, lens=(lens + 1) // 2)
+            z.backward(torch.ones_like(z) * 0.5 + z.detach() * 0.25)
+            names = {r["name"] for r in profiler.summary()}
+            profiler.enable(False); profiler.reset()
+        finally:
+            C._RESAMPLE = True
+        assert ({"conv4s2:fwd", "convt4s2:dgrad", "convt4s2:fwd", "conv4s2:dgrad"} <= names) == fast, sorted(names)
+        res.append((y.detach(), xa.grad, wa.grad, z.detach(), xb.grad, wb.grad))
+    for a, c in zip(*res):
+        assert torch.equal(a, c)

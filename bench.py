@@ -125,6 +125,8 @@ def launch_or_none(args, argv):
     if launcher.under_launcher() or args.gpus <= 1:
         return None
     visible = torch.cuda.device_count()          # does not initialise the GPU on this image
+    if visible < args.gpus and os.environ.get("SMT_BENCH_REHEARSAL") == "1" and visible >= 1:
+        visible = args.gpus                       # rehearsal of the N > 1 path on fewer cards (ranks share GPUs over gloo)
     if visible < args.gpus:
         print(f"bench.py: --gpus {args.gpus} but only {visible} GPU(s) visible on this node", file=sys.stderr)
         return 2
@@ -172,10 +174,13 @@ def main(argv=None):
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs MI355X GPUs (no CPU fallback for the hot path)")
+    rehearsal = os.environ.get("SMT_BENCH_REHEARSAL") == "1" and torch.cuda.device_count() < world
+    if rehearsal:
+        local = local % torch.cuda.device_count()   # several ranks per card: RCCL cannot do that, gloo carries the tensors
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group(backend="nccl", init_method="env://")
+        dist.init_process_group(backend="gloo" if rehearsal else "nccl", init_method="env://")
 
     from smt_amd import native, profiler
     native.lib()  # fail loudly if the HIP library is missing
@@ -320,6 +325,8 @@ def main(argv=None):
             "unit": "utterances/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "world_size": dist.get_world_size() if world > 1 else 1,
+            "backend": (dist.get_backend() if world > 1 else None),
+            "rehearsal_shared_gpu": bool(rehearsal),
             "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_step_per_rank": per_rank_ms,
             "grad_sync_exposed_ms_per_step": sync_ms,

@@ -1,0 +1,43 @@
+"""bench.py end to end on the GPU box: the one-line JSON contract at N = 1 and the self-launched N = 2 path (rehearsed with
+two ranks sharing the one card over gloo -- RCCL cannot put two ranks on one GPU; the driver's scaling run uses nccl)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--batch", "2", "--clip_len", "16384", "--steps", "2", "--warmup", "1", "--no_cpu_baseline", "--no_fp32"]
+
+
+def _run(args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, capture_output=True, text=True, env=e, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-500:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_the_contract_fields():
+    d = _run(SMALL)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["unit"] == "utterances/s" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert d["config"]["workload"].startswith("configs[1]") and d["roofline"]["bound"] in ("mfma", "hbm")
+    assert abs(d["value"] - 2 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]
+
+
+def test_two_ranks_started_by_bench_itself():
+    d = _run(["--gpus", "2"] + SMALL, env={"SMT_BENCH_REHEARSAL": "1"})
+    assert d["n_gpus"] == 2 and d["world_size"] == 2 and d["rehearsal_shared_gpu"] and d["backend"] == "gloo"
+    assert len(d["ms_per_step_per_rank"]) == 2 and d["grad_sync_exposed_ms_per_step"] is not None
+    assert abs(d["ms_per_step"] - max(d["ms_per_step_per_rank"])) < 1e-6          # MAX over ranks
+    assert abs(d["value"] - 4 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]    # whole-job utterances/s
+    assert d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"

@@ -295,6 +295,10 @@ def main(argv=None):
                                  "conv1x1_bwd_kernel"),
             "conv1x1_fold": group({"conv1x1_fold"}, "smt::conv1x1_fold_kernel (K3 + recomputed K1 residual, HBM-bound)",
                                   "hbm", dt, "conv1x1_fold_kernel"),
+            "conv_k3gate": group({"conv_k3gate"}, "smt::conv_k3gate_kernel (K3 of the four branches + gate, HBM-bound)", "hbm",
+                                 dt, "conv_k3gate_kernel"),
+            "resample": group({"conv4s2", "convt4s2"}, "smt::conv4s2_kernel / convt4s2_kernel (k4 s2 resampling convs, HBM-bound)",
+                              "hbm", dt),
             "conv_k1act": group({"conv_k1act"}, "smt::conv_k1act_kernel (K1, activated output only, HBM-bound)", "hbm",
                                 dt, "conv_k1act_kernel"),
             "conv_k1_bwd": group({"conv_k1_bwd"}, "smt::conv_k1_bwd_kernel (fused K1 backward, HBM-bound)", "hbm", dt,
@@ -312,6 +316,10 @@ def main(argv=None):
             "stft_loss": group({"stft_loss_fwd", "stft_loss_bwd"}, "smt::stft_loss_{fwd,bwd}_kernel", "hbm", "f32"),
         }
         extra_rooflines = {k: v for k, v in extra_rooflines.items() if v is not None}
+        if "stft_loss" in extra_rooflines:
+            extra_rooflines["stft_loss"]["note"] = ("not HBM-bound today: one frame per workgroup with a barrier per radix-4 "
+                                                    "pass makes it LDS-latency bound; frac is against the HBM bound its "
+                                                    "algorithmic bytes would allow")
         if "vq_forward" in extra_rooflines:
             # the north-star kernel against BOTH bounds: HBM by algorithmic bytes (above) and the bf16 matrix pipe by the
             # 3 x 2 N K D FLOP of its filter (its intensity, ~1500 FLOP/B at K = 1024, puts it on the MFMA side)

@@ -311,6 +311,65 @@ int smt_stft_loss_bwd(const float* y, const float* yh, const int* lens, const fl
 int smt_stft_inverse(const float* magnitude, const float* phase, const float* window, const float* twiddle, float* out,
                      int batch, int n_fft, int hop, int frames, smt_stream_t stream);
 
+/* ------------------------------------------------------- TransformerLM ---- */
+/* The kernels between the dense projections of the causal TransformerLM over VQ codes
+ * (models/transformer_lm/transformer_lm.py:32-135: nn.TransformerEncoder, post-norm layers, ReLU feed-forward).
+ * Activations are batch-major rows [batch, len, dim] f32 (the reference runs them [len, batch, dim]; the layout is
+ * internal to the model).  Every dropout site uses the counter-based generator above on the element's linear index
+ * in the tensor being dropped; thresh16 = 0 disables it (eval). */
+
+/* out = (emb[tokens] * mul + pe[position]) * keep   (transformer_lm.py:114-116, PositionalEncoding :27-29);
+ * tokens [batch, len] int64, emb [vocab_rows, dim], pe [>= len, dim].  bwd: demb [vocab_rows, dim] is zeroed and
+ * accumulated; row padding_idx receives nothing (nn.Embedding(padding_idx=PAD), :42-46). */
+int smt_lm_embed_fwd(const int64_t* tokens, const float* emb, const float* pe, float* out, int batch, int len, int dim,
+                     float mul, uint32_t drop_key, uint32_t drop_thresh16, float drop_scale, smt_stream_t stream);
+int smt_lm_embed_bwd(const int64_t* tokens, const float* dout, float* demb, int batch, int len, int dim, int vocab_rows,
+                     float mul, uint32_t drop_key, uint32_t drop_thresh16, float drop_scale, int64_t padding_idx,
+                     smt_stream_t stream);
+
+/* Multi-head self-attention core of nn.MultiheadAttention as the reference calls it (:110-111,117: additive causal
+ * mask triu(-inf, 1) plus the key-padding mask ~sequence_mask(lens)): head dim 32, len <= 512.
+ *   qkv [batch, len, 3*heads*32] = (q | k | v) rows as in_proj produces them;  lens [batch] int32 or NULL
+ *   ctx [batch, len, heads*32] = dropout(softmax(q k^T / sqrt(32) + masks)) v;   lse [batch, heads, len] (saved for bwd)
+ * key j is visible to query i iff (j <= i or causal == 0) and j < lens[b] -- causal = 0 is what `sample` runs
+ * (mask=None, :142); dropout index ((b*heads + h)*len + i)*len + j.
+ * bwd writes dqkv [batch, len, 3*heads*32] (every element). */
+int smt_lm_attention_fwd(const float* qkv, const int* lens, float* ctx, float* lse, int batch, int len, int heads,
+                         int causal, uint32_t drop_key, uint32_t drop_thresh16, float drop_scale, smt_stream_t stream);
+int smt_lm_attention_bwd(const float* qkv, const int* lens, const float* ctx, const float* lse, const float* dctx,
+                         float* dqkv, int batch, int len, int heads, int causal, uint32_t drop_key,
+                         uint32_t drop_thresh16, float drop_scale, smt_stream_t stream);
+
+/* y = LayerNorm(x + dropout(h)) * gamma + beta over the last dim (TransformerEncoderLayer, norm_first = False; with
+ * h = NULL the plain final LayerNorm of the encoder, :63-66); stats [rows, 2] = (mean, rstd).  dim = 64 * {1,2,4,8,12,
+ * 16,32}.  bwd: dx / dh may be NULL (not wanted); dgamma [2, dim] holds dgamma then dbeta (dbeta == dgamma + dim). */
+int smt_lm_add_ln_fwd(const float* x, const float* h, const float* gamma, const float* beta, float* y, float* stats,
+                      int64_t rows, int dim, float eps, uint32_t drop_key, uint32_t drop_thresh16, float drop_scale,
+                      smt_stream_t stream);
+size_t smt_lm_add_ln_bwd_workspace_bytes(int64_t rows, int dim);
+int smt_lm_add_ln_bwd(const float* x, const float* h, const float* dy, const float* gamma, const float* stats, float* dx,
+                      float* dh, float* dgamma, float* dbeta, int64_t rows, int dim, uint32_t drop_key,
+                      uint32_t drop_thresh16, float drop_scale, void* workspace, size_t workspace_bytes,
+                      smt_stream_t stream);
+
+/* h <- dropout(relu(h + bias)) in place (linear1 -> activation -> dropout of the feed-forward).  bwd: dh = da * keep *
+ * [a != 0] (a = the forward's result; dh may alias da), dbias [dim] = its column sums in a fixed order. */
+int smt_lm_bias_relu_fwd(float* h, const float* bias, int64_t rows, int dim, uint32_t drop_key, uint32_t drop_thresh16,
+                         float drop_scale, smt_stream_t stream);
+size_t smt_lm_bias_relu_bwd_workspace_bytes(int64_t rows, int dim);
+int smt_lm_bias_relu_bwd(const float* a, const float* da, float* dh, float* dbias, int64_t rows, int dim, uint32_t drop_key,
+                         uint32_t drop_thresh16, float drop_scale, void* workspace, size_t workspace_bytes,
+                         smt_stream_t stream);
+
+/* Next-token cross entropy and accuracy (:121-128).  target [rows] int64, < 0 = row not counted (the reference's
+ * loss_mask); row_out [rows, 2] = (logsumexp - logit[target] or 0, argmax == target as 0/1, lowest index on ties);
+ * lse [rows].  bwd: dlogits = coef[0] * (softmax - onehot) on counted rows, 0 elsewhere; coef is a DEVICE scalar
+ * (upstream gradient / number of counted rows). */
+int smt_lm_ce_fwd(const float* logits, const int64_t* target, float* row_out, float* lse, int64_t rows, int vocab,
+                  smt_stream_t stream);
+int smt_lm_ce_bwd(const float* logits, const int64_t* target, const float* lse, const float* coef, float* dlogits,
+                  int64_t rows, int vocab, smt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,7 @@ _lock = threading.Lock()
 c_i64 = ctypes.c_int64
 c_int = ctypes.c_int
 c_f32 = ctypes.c_float
+c_u32 = ctypes.c_uint32
 c_ptr = ctypes.c_void_p
 c_size = ctypes.c_size_t
 
@@ -71,6 +72,22 @@ _SIGNATURES = {
     "smt_stft_inverse": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "smt_conv_out_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr,
                                  c_size, c_ptr]),
+    "smt_lm_embed_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_f32, c_u32, c_u32, c_f32, c_ptr]),
+    "smt_lm_embed_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_f32, c_u32, c_u32, c_f32, c_i64,
+                                 c_ptr]),
+    "smt_lm_attention_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_u32, c_u32, c_f32, c_ptr]),
+    "smt_lm_attention_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_u32, c_u32, c_f32,
+                                     c_ptr]),
+    "smt_lm_add_ln_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_u32, c_u32, c_f32,
+                                  c_ptr]),
+    "smt_lm_add_ln_bwd_workspace_bytes": (c_size, [c_i64, c_int]),
+    "smt_lm_add_ln_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_u32,
+                                  c_u32, c_f32, c_ptr, c_size, c_ptr]),
+    "smt_lm_bias_relu_fwd": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_u32, c_u32, c_f32, c_ptr]),
+    "smt_lm_bias_relu_bwd_workspace_bytes": (c_size, [c_i64, c_int]),
+    "smt_lm_bias_relu_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_u32, c_u32, c_f32, c_ptr, c_size, c_ptr]),
+    "smt_lm_ce_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr]),
+    "smt_lm_ce_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr]),
 }
 
 

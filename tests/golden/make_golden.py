@@ -501,12 +501,60 @@ def gen_mas():
     save("mas", value=value, mask=mask, path=path, x_len=x_len, y_len=y_len)
 
 
+def gen_transformer_lm():
+    """models/transformer_lm/transformer_lm.py:32-135, the reference's own TransformerLM on a small config (2 layers,
+    d_model 64, 2 heads of 32, feed-forward 128, vocab 16), dropout 0 (its dropout is torch's global RNG), ragged lengths.
+    The module imports OmegaConf for `load_vqvae` only: omegaconf is absent, so an empty module carrying the two NAMES lets
+    the import line resolve, and `load_vqvae` (disk access, the VQ-VAE is not on the scored path) is replaced by an empty
+    ModuleDict -- nothing of omegaconf is called.  Captured: logits (classifier output), loss, accuracy, all gradients."""
+    from oracle import lm_oracle
+    om = types.ModuleType("omegaconf")
+    om.OmegaConf = type("OmegaConf", (), {})
+    om.DictConfig = dict
+    sys.modules.setdefault("omegaconf", om)
+    from models.transformer_lm.transformer_lm import TransformerLM
+    TransformerLM.load_vqvae = staticmethod(lambda log_dir, ckpt_num: torch.nn.ModuleDict())
+    cfg = wrap({"model": dict(vocab_size=16, embed_dim=64, max_len=64, num_layers=2, d_model=64, nhead=2, dim_feedforward=128,
+                              dropout=0.0, activation="relu", layer_norm_eps=1e-5, norm_first=False, loss_type="ce",
+                              vqvae=dict(log_dir="", ckpt_num=0))})
+    torch.manual_seed(111)
+    model = TransformerLM(cfg)
+    # nn.TransformerEncoder clones one layer: perturb so that the two layers (and the LayerNorm affine maps) differ
+    g = torch.Generator().manual_seed(112)
+    with torch.no_grad():
+        for name, prm in model.named_parameters():
+            if name != "embedding.weight":
+                prm.add_(torch.randn(prm.shape, generator=g) * 0.05)
+    model.train()
+    x, lens = lm_oracle.synthetic_tokens(3, 12, 16, seed=116)
+    x[2, 5] = lm_oracle.BOS          # a special token inside a sequence: not scored (loss_mask, :124)
+    captured = {}
+    hook = model.classifier.register_forward_hook(lambda mod, inp, out: captured.__setitem__("xh", out.detach()))
+    loss_dict, metrics = model(x, lens, None, None)
+    hook.remove()
+    loss_dict["loss"].backward()
+    params = {k: v.detach().clone() for k, v in model.state_dict().items() if k != "pos_encoding.pe"}
+    grads = {"grad." + k: v.grad.detach().clone() for k, v in model.named_parameters()}
+    logits = captured["xh"].permute(1, 0, 2).contiguous()              # [L, B, V] -> [B, L, V]
+    # the restatement against the reference
+    p64 = {k: v.double() for k, v in params.items()}
+    mine = lm_oracle.lm_logits(x, lens, p64, heads=2, num_layers=2)
+    ml, ma = lm_oracle.lm_loss(x, mine)
+    print("  oracle vs ref: logits", float((mine.float() - logits).abs().max()), "loss", float(ml) - loss_dict["loss"].item(),
+          "acc", float(ma), float(metrics["accuracy"]))
+    assert torch.allclose(mine.float(), logits, atol=2e-5) and abs(float(ml) - loss_dict["loss"].item()) < 1e-5
+    assert torch.equal(model.pos_encoding.pe[:, 0], lm_oracle.positional_table(64, 64))
+    save("transformer_lm", x=x, lens=lens, logits=logits, loss=loss_dict["loss"].detach(), accuracy=metrics["accuracy"],
+         **{"param." + k: v for k, v in params.items()}, **grads)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     only = set(sys.argv[1:])
     for name, fn in [("stft", gen_stft), ("mel", gen_mel), ("vq", gen_vq), ("vq_forward", gen_vq_forward),
                      ("block", gen_block), ("losses", gen_losses), ("model", gen_model),
-                     ("model_train", gen_model_train_krand), ("ema", gen_ema), ("mas", gen_mas), ("stft_inverse", gen_stft_inverse)]:
+                     ("model_train", gen_model_train_krand), ("ema", gen_ema), ("mas", gen_mas), ("stft_inverse", gen_stft_inverse),
+                     ("transformer_lm", gen_transformer_lm)]:
         if only and name not in only:
             continue
         print(f"[{name}]")

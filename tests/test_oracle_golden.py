@@ -243,3 +243,39 @@ def test_stft_inverse_oracle_matches_reference_golden(golden):
         assert torch.allclose(y, torch.from_numpy(g[f"{tag}_y"]), atol=1e-6)
         x = torch.from_numpy(g[f"{tag}_x"])
         assert (y[:, 0, n_fft:-n_fft] - x[:, n_fft:y.shape[-1] - n_fft]).abs().max() < 5e-6
+
+
+def _lm_fixture(golden):
+    g = golden("transformer_lm")
+    params = {k[len("param."):]: torch.from_numpy(g[k]) for k in g if k.startswith("param.")}
+    grads = {k[len("grad."):]: torch.from_numpy(g[k]) for k in g if k.startswith("grad.")}
+    return g, params, grads
+
+
+def test_transformer_lm_oracle_matches_reference_golden(golden):
+    """transformer_lm.py:109-135 run by the reference's own class (dropout 0): logits, loss, accuracy and every gradient."""
+    from oracle import lm_oracle as lmo
+    g, params, grads = _lm_fixture(golden)
+    x, lens = torch.from_numpy(g["x"]), torch.from_numpy(g["lens"])
+    p = {k: v.double().requires_grad_(True) for k, v in params.items()}
+    logits = lmo.lm_logits(x, lens, p, heads=2, num_layers=2)
+    loss, acc = lmo.lm_loss(x, logits)
+    assert torch.allclose(logits.float(), torch.from_numpy(g["logits"]), atol=1e-5)
+    assert abs(loss.item() - float(g["loss"])) < 1e-6 and abs(acc.item() - float(g["accuracy"])) < 1e-7
+    loss.backward()
+    for name, ref in grads.items():
+        if name.startswith("vqvae."):
+            continue
+        mine = p[name].grad.float()
+        assert torch.allclose(mine, ref, atol=2e-6, rtol=1e-4), (name, float((mine - ref).abs().max()))
+    assert float(grads["embedding.weight"][lmo.PAD].abs().max()) == 0.0       # padding_idx row: no gradient
+
+
+def test_transformer_lm_oracle_dropout_sites_are_unbiased():
+    from oracle import lm_oracle as lmo
+    drop = lmo.CounterDropout(seed=3, p=0.1)
+    x = torch.ones(4, 2, 33, 33)
+    a, b = drop(1, x), drop(5, x)
+    assert abs(float(a.mean()) - 1.0) < 0.02 and set(a.unique().tolist()) == {0.0, float(np.float32(1) / np.float32(0.9))}
+    assert not torch.equal(a, b)                                    # sites draw different masks
+    assert torch.equal(lmo.CounterDropout(seed=3, p=0.0)(1, x), x)

@@ -11,9 +11,7 @@
 //
 // Activations are [B, L, C] fp32 rows (the fp32 parity path; L <= 512, head dim 32).  Dropout masks come from the
 // counter-based generator of include/smt_hip.h ("dropout"): keep(i) of the element's linear index under a per-site key,
-// so the backward kernels recompute them.  Attention: one workgroup per (batch, head); K and V of the head sit in LDS,
-// a thread owns one query row (workgroup = L rounded up to whole waves) and walks its causal prefix with an online softmax -- at L = 258, dh = 32 a head is
-// 2 MFLOP, far below anything worth tiling for the matrix pipe; the layer's time is in the GEMMs and launches.
+// so the backward kernels recompute them.
 #include <algorithm>
 
 #include "conv_common.h"
@@ -51,137 +49,211 @@ __global__ __launch_bounds__(256) void lm_embed_bwd_kernel(const long long* __re
 
 // ------------------------------------------------------------------------------------------------ attention
 // qkv [B, L, 3 d] (q | k | v, heads side by side inside each), ctx [B, L, d], lse [B, H, L] (log-sum-exp of the scaled,
-// masked scores).  Key j is visible to query i iff (j <= i or not causal) and j < lens[b].  Attention-weight dropout: element index
-// ((b H + h) L + i) L + j.
-constexpr int LM_DH = 32, LM_MAXL = 512;
+// masked scores).  Key j is visible to query i iff (j <= i or not causal) and j < lens[b].  Attention-weight dropout:
+// element index ((b H + h) L + i) L + j.
+//
+// Work split (all three kernels): a workgroup owns 64 consecutive rows of one (batch, head) -- queries in the forward and
+// the dq kernel, keys in the dk/dv kernel -- and AT_G = 4 adjacent lanes share a row, lane g walking the opposite index
+// j = g, g + 4, ...; the four partial results meet in two xor-shuffles.  The opposite side (K, V or scaled Q, dctx) sits in
+// LDS at a pitch of 36 floats: the four rows a lane group reads at once fall into disjoint bank groups, and the 16 groups
+// of a wave read the same four rows (broadcast).  B H ceil(L / 64) workgroups (640 at the reference's 8 x 16 x 258) of four
+// waves fill the chip; the causal triangle makes later tiles longer, so tiles are issued longest first.
+constexpr int LM_DH = 32, LM_MAXL = 512, AT_G = 4, AT_ROWS = 64, AT_LD = 36;
 
-__global__ __launch_bounds__(512) void lm_attn_fwd_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
-                                                          float* __restrict__ ctx, float* __restrict__ lse, int L, int H,
-                                                          int causal, unsigned key, unsigned thr, float dscale) {
-  extern __shared__ float sm[];                               // K [L][33] | V [L][33]
-  float* ks = sm;
-  float* vs = sm + (size_t)L * 33;
-  const int b = blockIdx.x / H, h = blockIdx.x % H, d = H * LM_DH;
-  const float* base = qkv + (size_t)b * L * 3 * d;
-  for (int f = threadIdx.x; f < L * LM_DH; f += blockDim.x) {
-    const int j = f / LM_DH, c = f % LM_DH;
-    ks[j * 33 + c] = base[(size_t)j * 3 * d + d + h * LM_DH + c];
-    vs[j * 33 + c] = base[(size_t)j * 3 * d + 2 * d + h * LM_DH + c];
-  }
-  __syncthreads();
-  const int len = lens ? min(lens[b], L) : L;
-  const float sc = rsqrtf((float)LM_DH);
-  for (int i = threadIdx.x; i < L; i += blockDim.x) {
-    float q[LM_DH], acc[LM_DH];
-#pragma unroll
-    for (int c = 0; c < LM_DH; ++c) { q[c] = base[(size_t)i * 3 * d + h * LM_DH + c] * sc; acc[c] = 0.f; }
-    float m = -INFINITY, z = 0.f;
-    const int jn = causal ? min(i + 1, len) : len;
-    const unsigned long long e0 = (((unsigned long long)b * H + h) * L + i) * L;
-    for (int j = 0; j < jn; ++j) {
-      float s = 0.f;
-#pragma unroll
-      for (int c = 0; c < LM_DH; ++c) s = fmaf(q[c], ks[j * 33 + c], s);
-      const float mn = fmaxf(m, s);
-      const float corr = __expf(m - mn), p = __expf(s - mn);
-      z = z * corr + p;
-      const float pk = p * lm_keep(e0 + j, key, thr, dscale);
-#pragma unroll
-      for (int c = 0; c < LM_DH; ++c) acc[c] = acc[c] * corr + pk * vs[j * 33 + c];
-      m = mn;
-    }
-    const float inv = jn > 0 ? 1.f / z : 0.f;
-#pragma unroll
-    for (int c = 0; c < LM_DH; ++c) ctx[((size_t)b * L + i) * d + h * LM_DH + c] = acc[c] * inv;
-    lse[((size_t)b * H + h) * L + i] = jn > 0 ? m + __logf(z) : 0.f;
+// stage `n` rows of width 32 from global (row pitch `pitch` floats) into LDS rows of AT_LD floats, times `mul`
+__device__ __forceinline__ void at_stage(float* dst, const float* __restrict__ src, size_t pitch, int n, float mul) {
+  for (int f = threadIdx.x; f < n * 8; f += 256) {
+    const int j = f >> 3, c4 = f & 7;
+    f32x4 v = *(const f32x4*)(src + (size_t)j * pitch + c4 * 4);
+    *(f32x4*)(dst + j * AT_LD + c4 * 4) = v * mul;
   }
 }
+__device__ __forceinline__ float at_dot(const float* __restrict__ row, const float (&q)[LM_DH]) {
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < LM_DH; c += 8) {
+    const f32x4 a = *(const f32x4*)(row + c), b = *(const f32x4*)(row + c + 4);
+    s0 = fmaf(q[c], a.x, s0); s0 = fmaf(q[c + 1], a.y, s0); s0 = fmaf(q[c + 2], a.z, s0); s0 = fmaf(q[c + 3], a.w, s0);
+    s1 = fmaf(q[c + 4], b.x, s1); s1 = fmaf(q[c + 5], b.y, s1); s1 = fmaf(q[c + 6], b.z, s1); s1 = fmaf(q[c + 7], b.w, s1);
+  }
+  return s0 + s1;
+}
+__device__ __forceinline__ void at_axpy(float (&acc)[LM_DH], float a, const float* __restrict__ row) {
+#pragma unroll
+  for (int c = 0; c < LM_DH; c += 4) {
+    const f32x4 v = *(const f32x4*)(row + c);
+    acc[c] = fmaf(a, v.x, acc[c]); acc[c + 1] = fmaf(a, v.y, acc[c + 1]);
+    acc[c + 2] = fmaf(a, v.z, acc[c + 2]); acc[c + 3] = fmaf(a, v.w, acc[c + 3]);
+  }
+}
+__device__ __forceinline__ void at_load_row(float (&r)[LM_DH], const float* __restrict__ src, float mul) {
+#pragma unroll
+  for (int c = 0; c < LM_DH; c += 4) {
+    const f32x4 v = *(const f32x4*)(src + c);
+    r[c] = v.x * mul; r[c + 1] = v.y * mul; r[c + 2] = v.z * mul; r[c + 3] = v.w * mul;
+  }
+}
+// lane g of the group keeps channels [8 g, 8 g + 8) of the group sum of acc
+__device__ __forceinline__ void at_group_sum_store(float (&acc)[LM_DH], int g, float mul, float* __restrict__ dst) {
+#pragma unroll
+  for (int c = 0; c < LM_DH; ++c) {
+    acc[c] += __shfl_xor(acc[c], 1, 64);
+    acc[c] += __shfl_xor(acc[c], 2, 64);
+  }
+  f32x4 o0, o1;
+#pragma unroll
+  for (int gg = 0; gg < AT_G; ++gg)
+    if (g == gg) {
+      o0 = f32x4{acc[8 * gg], acc[8 * gg + 1], acc[8 * gg + 2], acc[8 * gg + 3]} * mul;
+      o1 = f32x4{acc[8 * gg + 4], acc[8 * gg + 5], acc[8 * gg + 6], acc[8 * gg + 7]} * mul;
+    }
+  *(f32x4*)(dst + 8 * g) = o0;
+  *(f32x4*)(dst + 8 * g + 4) = o1;
+}
 
-// dqkv from dctx: P_ij = exp(s_ij - lse_i); dPd_ij = dctx_i . v_j; delta_i = sum_j P_ij keep_ij dPd_ij = dctx_i . ctx_i;
+__global__ __launch_bounds__(256) void lm_attn_fwd_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
+                                                          float* __restrict__ ctx, float* __restrict__ lse, int L, int H,
+                                                          int causal, unsigned key, unsigned thr, float dscale) {
+  extern __shared__ float sm[];                               // K [nk][36] | V [nk][36]
+  const int tile = gridDim.x - 1 - blockIdx.x;                // longest (last) tiles first
+  const int b = blockIdx.y / H, h = blockIdx.y % H, d = H * LM_DH;
+  const float* base = qkv + (size_t)b * L * 3 * d + h * LM_DH;
+  const int len = lens ? max(0, min(lens[b], L)) : L;
+  const int nk = causal ? min(len, min(L, (tile + 1) * AT_ROWS)) : len;   // keys any row of this tile can see
+  float* ks = sm;
+  float* vs = sm + (size_t)nk * AT_LD;
+  at_stage(ks, base + d, 3 * (size_t)d, nk, 1.f);
+  at_stage(vs, base + 2 * d, 3 * (size_t)d, nk, 1.f);
+  __syncthreads();
+  const int g = threadIdx.x & (AT_G - 1), i = tile * AT_ROWS + (threadIdx.x >> 2);
+  if (i >= L) return;                                         // whole lane groups leave together
+  float q[LM_DH], acc[LM_DH];
+  at_load_row(q, base + (size_t)i * 3 * d, rsqrtf((float)LM_DH));
+#pragma unroll
+  for (int c = 0; c < LM_DH; ++c) acc[c] = 0.f;
+  float m = -INFINITY, z = 0.f;
+  const int jn = causal ? min(i + 1, len) : len;
+  const unsigned long long e0 = (((unsigned long long)b * H + h) * L + i) * L;
+  for (int j = g; j < jn; j += AT_G) {
+    const float s = at_dot(ks + j * AT_LD, q);
+    if (s > m) {                                              // new running maximum: rescale what is accumulated
+      const float corr = __expf(m - s);
+      z *= corr;
+#pragma unroll
+      for (int c = 0; c < LM_DH; ++c) acc[c] *= corr;
+      m = s;
+    }
+    const float p = __expf(s - m);
+    z += p;
+    at_axpy(acc, p * lm_keep(e0 + j, key, thr, dscale), vs + j * AT_LD);
+  }
+  // merge the four partial softmaxes of the row
+  float mm = fmaxf(m, __shfl_xor(m, 1, 64));
+  mm = fmaxf(mm, __shfl_xor(mm, 2, 64));
+  const float sc = (m == -INFINITY) ? 0.f : __expf(m - mm);
+  z *= sc;
+  z += __shfl_xor(z, 1, 64);
+  z += __shfl_xor(z, 2, 64);
+#pragma unroll
+  for (int c = 0; c < LM_DH; ++c) acc[c] *= sc;
+  at_group_sum_store(acc, g, jn > 0 ? 1.f / z : 0.f, ctx + ((size_t)b * L + i) * d + h * LM_DH);
+  if (g == 0) lse[((size_t)b * H + h) * L + i] = jn > 0 ? mm + __logf(z) : 0.f;
+}
+
+// Backward: P_ij = exp(s_ij - lse_i); dPd_ij = dctx_i . v_j; delta_i = sum_j P_ij keep_ij dPd_ij = dctx_i . ctx_i;
 // dS_ij = P_ij (keep_ij dPd_ij - delta_i); dq_i = sum_j dS_ij k_j / sqrt(dh); dk_j = sum_i dS_ij q_i / sqrt(dh);
-// dv_j = sum_i P_ij keep_ij dctx_i.  Pass 1: a thread per query (dq); pass 2: a thread per key (dk, dv).
-__global__ __launch_bounds__(512) void lm_attn_bwd_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
+// dv_j = sum_i P_ij keep_ij dctx_i.  dq: query tiles against K, V in LDS.
+__global__ __launch_bounds__(256) void lm_attn_dq_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
+                                                         const float* __restrict__ ctx, const float* __restrict__ lse,
+                                                         const float* __restrict__ dctx, float* __restrict__ dqkv, int L, int H,
+                                                         int causal, unsigned key, unsigned thr, float dscale) {
+  extern __shared__ float sm[];
+  const int tile = gridDim.x - 1 - blockIdx.x;
+  const int b = blockIdx.y / H, h = blockIdx.y % H, d = H * LM_DH;
+  const float* base = qkv + (size_t)b * L * 3 * d + h * LM_DH;
+  const int len = lens ? max(0, min(lens[b], L)) : L;
+  const int nk = causal ? min(len, min(L, (tile + 1) * AT_ROWS)) : len;
+  float* ks = sm;
+  float* vs = sm + (size_t)nk * AT_LD;
+  at_stage(ks, base + d, 3 * (size_t)d, nk, 1.f);
+  at_stage(vs, base + 2 * d, 3 * (size_t)d, nk, 1.f);
+  __syncthreads();
+  const int g = threadIdx.x & (AT_G - 1), i = tile * AT_ROWS + (threadIdx.x >> 2);
+  if (i >= L) return;
+  const float sc = rsqrtf((float)LM_DH);
+  float q[LM_DH], go[LM_DH], dq[LM_DH];
+  at_load_row(q, base + (size_t)i * 3 * d, sc);
+  at_load_row(go, dctx + ((size_t)b * L + i) * d + h * LM_DH, 1.f);
+  const float dl = at_dot(ctx + ((size_t)b * L + i) * d + h * LM_DH, go);
+#pragma unroll
+  for (int c = 0; c < LM_DH; ++c) dq[c] = 0.f;
+  const float li = lse[((size_t)b * H + h) * L + i];
+  const int jn = causal ? min(i + 1, len) : len;
+  const unsigned long long e0 = (((unsigned long long)b * H + h) * L + i) * L;
+  for (int j = g; j < jn; j += AT_G) {
+    const float p = __expf(at_dot(ks + j * AT_LD, q) - li);
+    const float dp = at_dot(vs + j * AT_LD, go);
+    at_axpy(dq, p * (lm_keep(e0 + j, key, thr, dscale) * dp - dl), ks + j * AT_LD);
+  }
+  at_group_sum_store(dq, g, sc, dqkv + ((size_t)b * L + i) * 3 * d + h * LM_DH);
+}
+
+// dk, dv: key tiles against the scaled queries and dctx (plus lse, delta per query) in LDS.
+__global__ __launch_bounds__(256) void lm_attn_dkv_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
                                                           const float* __restrict__ ctx, const float* __restrict__ lse,
                                                           const float* __restrict__ dctx, float* __restrict__ dqkv, int L, int H,
                                                           int causal, unsigned key, unsigned thr, float dscale) {
-  extern __shared__ float sm[];                               // A [L][33] | Bm [L][33] | delta [L] | lse [L]
-  float* as = sm;
-  float* bs = sm + (size_t)L * 33;
-  float* delta = bs + (size_t)L * 33;
-  float* ls = delta + L;
-  const int b = blockIdx.x / H, h = blockIdx.x % H, d = H * LM_DH;
-  const float* base = qkv + (size_t)b * L * 3 * d;
-  float* dbase = dqkv + (size_t)b * L * 3 * d;
-  const int len = lens ? min(lens[b], L) : L;
-  const float sc = rsqrtf((float)LM_DH);
-  // pass 1: K, V in LDS; thread per query
-  for (int f = threadIdx.x; f < L * LM_DH; f += blockDim.x) {
-    const int j = f / LM_DH, c = f % LM_DH;
-    as[j * 33 + c] = base[(size_t)j * 3 * d + d + h * LM_DH + c];
-    bs[j * 33 + c] = base[(size_t)j * 3 * d + 2 * d + h * LM_DH + c];
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < L; i += blockDim.x) {
-    float q[LM_DH], go[LM_DH], dq[LM_DH];
-    float dl = 0.f;
-#pragma unroll
-    for (int c = 0; c < LM_DH; ++c) {
-      q[c] = base[(size_t)i * 3 * d + h * LM_DH + c] * sc;
-      go[c] = dctx[((size_t)b * L + i) * d + h * LM_DH + c];
-      dl = fmaf(go[c], ctx[((size_t)b * L + i) * d + h * LM_DH + c], dl);
-      dq[c] = 0.f;
-    }
-    const float li = lse[((size_t)b * H + h) * L + i];
-    delta[i] = dl; ls[i] = li;
-    const int jn = causal ? min(i + 1, len) : len;
-    const unsigned long long e0 = (((unsigned long long)b * H + h) * L + i) * L;
-    for (int j = 0; j < jn; ++j) {
-      float s = 0.f, dp = 0.f;
-#pragma unroll
-      for (int c = 0; c < LM_DH; ++c) { s = fmaf(q[c], as[j * 33 + c], s); dp = fmaf(go[c], bs[j * 33 + c], dp); }
-      const float p = __expf(s - li);
-      const float ds = p * (lm_keep(e0 + j, key, thr, dscale) * dp - dl);
-#pragma unroll
-      for (int c = 0; c < LM_DH; ++c) dq[c] = fmaf(ds, as[j * 33 + c], dq[c]);
-    }
-#pragma unroll
-    for (int c = 0; c < LM_DH; ++c) dbase[(size_t)i * 3 * d + h * LM_DH + c] = dq[c] * sc;
-  }
-  __syncthreads();
-  // pass 2: Q (scaled), dctx in LDS; thread per key
-  for (int f = threadIdx.x; f < L * LM_DH; f += blockDim.x) {
-    const int i = f / LM_DH, c = f % LM_DH;
-    as[i * 33 + c] = base[(size_t)i * 3 * d + h * LM_DH + c] * sc;
-    bs[i * 33 + c] = dctx[((size_t)b * L + i) * d + h * LM_DH + c];
-  }
-  __syncthreads();
-  for (int j = threadIdx.x; j < L; j += blockDim.x) {
-    float kk[LM_DH], vv[LM_DH], dk[LM_DH], dv[LM_DH];
-#pragma unroll
-    for (int c = 0; c < LM_DH; ++c) {
-      kk[c] = base[(size_t)j * 3 * d + d + h * LM_DH + c];
-      vv[c] = base[(size_t)j * 3 * d + 2 * d + h * LM_DH + c];
-      dk[c] = 0.f; dv[c] = 0.f;
-    }
-    if (j < len) {
-      for (int i = causal ? j : 0; i < L; ++i) {              // queries that see key j
-        float s = 0.f, dp = 0.f;
-#pragma unroll
-        for (int c = 0; c < LM_DH; ++c) { s = fmaf(as[i * 33 + c], kk[c], s); dp = fmaf(bs[i * 33 + c], vv[c], dp); }
-        const float p = __expf(s - ls[i]);
-        const float kp = lm_keep((((unsigned long long)b * H + h) * L + i) * L + j, key, thr, dscale);
-        const float ds = p * (kp * dp - delta[i]);
-        const float pv = p * kp;
-#pragma unroll
-        for (int c = 0; c < LM_DH; ++c) { dk[c] = fmaf(ds, as[i * 33 + c], dk[c]); dv[c] = fmaf(pv, bs[i * 33 + c], dv[c]); }
+  extern __shared__ float sm[];                               // Q [nq][36] | dO [nq][36] | lse [nq] | delta [nq]
+  const int tile = blockIdx.x;                                // first key tiles see the most queries: already longest first
+  const int b = blockIdx.y / H, h = blockIdx.y % H, d = H * LM_DH;
+  const float* base = qkv + (size_t)b * L * 3 * d + h * LM_DH;
+  float* dbase = dqkv + (size_t)b * L * 3 * d + h * LM_DH;
+  const int len = lens ? max(0, min(lens[b], L)) : L;
+  const int i0 = causal ? tile * AT_ROWS : 0, nq = L - i0;    // queries [i0, L) can see keys of this tile
+  const int g = threadIdx.x & (AT_G - 1), j = tile * AT_ROWS + (threadIdx.x >> 2);
+  float* qs = sm;
+  float* gs = qs + (size_t)nq * AT_LD;
+  float* ls = gs + (size_t)nq * AT_LD;
+  float* delta = ls + nq;
+  const bool tile_live = tile * AT_ROWS < len;                // uniform: any visible key in this tile at all?
+  if (tile_live) {
+    const float sc = rsqrtf((float)LM_DH);
+    at_stage(qs, base + (size_t)i0 * 3 * d, 3 * (size_t)d, nq, sc);
+    const float* gsrc = dctx + ((size_t)b * L + i0) * d + h * LM_DH;
+    const float* csrc = ctx + ((size_t)b * L + i0) * d + h * LM_DH;
+    for (int f = threadIdx.x; f < ((nq * 8 + 63) & ~63); f += 256) {      // whole waves: the shuffles below need all 8 lanes
+      const int r = f >> 3, c4 = f & 7;
+      float part = 0.f;
+      if (r < nq) {
+        const f32x4 gv = *(const f32x4*)(gsrc + (size_t)r * d + c4 * 4), cv = *(const f32x4*)(csrc + (size_t)r * d + c4 * 4);
+        *(f32x4*)(gs + r * AT_LD + c4 * 4) = gv;
+        part = gv.x * cv.x + gv.y * cv.y + gv.z * cv.z + gv.w * cv.w;
       }
-    }
-#pragma unroll
-    for (int c = 0; c < LM_DH; ++c) {
-      dbase[(size_t)j * 3 * d + d + h * LM_DH + c] = dk[c];    // q in LDS already carries 1/sqrt(dh)
-      dbase[(size_t)j * 3 * d + 2 * d + h * LM_DH + c] = dv[c];
+      part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);
+      if (r < nq && c4 == 0) { delta[r] = part; ls[r] = lse[((size_t)b * H + h) * L + i0 + r]; }
     }
   }
+  __syncthreads();
+  if (j >= L) return;
+  float dk[LM_DH], dv[LM_DH];
+#pragma unroll
+  for (int c = 0; c < LM_DH; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
+  if (j < len) {
+    float kk[LM_DH], vv[LM_DH];
+    at_load_row(kk, base + (size_t)j * 3 * d + d, 1.f);
+    at_load_row(vv, base + (size_t)j * 3 * d + 2 * d, 1.f);
+    const int r0 = causal ? (j - i0) : 0;                     // first query row (relative to i0) that sees key j
+    for (int r = (r0 & ~(AT_G - 1)) + g; r < nq; r += AT_G) {
+      if (r < r0) continue;
+      const float p = __expf(at_dot(qs + r * AT_LD, kk) - ls[r]);
+      const float kp = lm_keep((((unsigned long long)b * H + h) * L + i0 + r) * L + j, key, thr, dscale);
+      const float dp = at_dot(gs + r * AT_LD, vv);
+      at_axpy(dk, p * (kp * dp - delta[r]), qs + r * AT_LD);   // q in LDS already carries 1/sqrt(dh)
+      at_axpy(dv, p * kp, gs + r * AT_LD);
+    }
+  }
+  at_group_sum_store(dk, g, 1.f, dbase + (size_t)j * 3 * d + d);
+  at_group_sum_store(dv, g, 1.f, dbase + (size_t)j * 3 * d + 2 * d);
 }
 
 // ------------------------------------------------------------------------------------------------ add + LayerNorm
@@ -217,7 +289,8 @@ __global__ __launch_bounds__(256) void lm_add_ln_fwd_kernel(const float* __restr
   if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
 }
 // xhat recomputed from (x, h, stats); g = dy gamma; dpre = rstd (g - mean(g) - xhat mean(g xhat)); dx = dpre (if dx),
-// dh = dpre * mask (if dh); dgamma / dbeta partials per workgroup (4 rows) -> part [nwg][2][C]
+// dh = dpre * mask (if dh); dgamma / dbeta partials per workgroup (LN_RPB rows, LN_RPB / 4 per wave) -> part [nwg][2][C]
+constexpr int LN_RPB = 16;
 template <int PER>
 __global__ __launch_bounds__(256) void lm_add_ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ hh,
                                                             const float* __restrict__ dy, const float* __restrict__ gamma,
@@ -227,28 +300,25 @@ __global__ __launch_bounds__(256) void lm_add_ln_bwd_kernel(const float* __restr
   constexpr int C = PER * 64;
   extern __shared__ float red[];                              // [4][2][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long long row = (long long)blockIdx.x * 4 + wave;
-  const bool live = row < rows;
-  float xh[PER], g[PER];
-  float sg = 0.f, sgx = 0.f;
-  const float mean = live ? stats[2 * row] : 0.f, rstd = live ? stats[2 * row + 1] : 0.f;
+  float pg[PER], pb[PER], gm[PER];
 #pragma unroll
-  for (int q = 0; q < PER; ++q) {
-    const int c = lane + 64 * q;
-    float xv = 0.f, gv = 0.f, dyv = 0.f;
-    if (live) {
-      const long long e = row * C + c;
-      dyv = dy[e];
+  for (int q = 0; q < PER; ++q) { pg[q] = 0.f; pb[q] = 0.f; gm[q] = gamma[lane + 64 * q]; }
+  for (int rr = 0; rr < LN_RPB / 4; ++rr) {
+    const long long row = (long long)blockIdx.x * LN_RPB + wave * (LN_RPB / 4) + rr;
+    if (row >= rows) break;                                   // wave-uniform
+    float xh[PER], g[PER];
+    float sg = 0.f, sgx = 0.f;
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const long long e = row * C + lane + 64 * q;
+      const float dyv = dy[e];
       const float pre = (x ? x[e] : 0.f) + (hh ? hh[e] * lm_keep((unsigned long long)e, key, thr, dscale) : 0.f);
-      xv = (pre - mean) * rstd;
-      gv = dyv * gamma[c];
+      const float xv = (pre - mean) * rstd, gv = dyv * gm[q];
+      xh[q] = xv; g[q] = gv; sg += gv; sgx = fmaf(gv, xv, sgx);
+      pg[q] = fmaf(dyv, xv, pg[q]); pb[q] += dyv;
     }
-    xh[q] = xv; g[q] = gv; sg += gv; sgx = fmaf(gv, xv, sgx);
-    red[(wave * 2 + 0) * C + c] = dyv * xv;
-    red[(wave * 2 + 1) * C + c] = dyv;
-  }
-  sg = wave_sum(sg) / (float)C; sgx = wave_sum(sgx) / (float)C;
-  if (live) {
+    sg = wave_sum(sg) / (float)C; sgx = wave_sum(sgx) / (float)C;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
       const long long e = row * C + lane + 64 * q;
@@ -256,6 +326,11 @@ __global__ __launch_bounds__(256) void lm_add_ln_bwd_kernel(const float* __restr
       if (dx) dx[e] = dpre;
       if (dh) dh[e] = dpre * lm_keep((unsigned long long)e, key, thr, dscale);
     }
+  }
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    red[(wave * 2 + 0) * C + lane + 64 * q] = pg[q];
+    red[(wave * 2 + 1) * C + lane + 64 * q] = pb[q];
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -273,15 +348,21 @@ __global__ __launch_bounds__(256) void lm_add_ln_bwd_kernel(const float* __restr
     case 32: CALL(32); break;                                                           \
     default: SMT_CHECK_ARG(false, "add_ln: dim %d not built (64 x {1,2,4,8,12,16,32})", (int)(dim)); \
   }
-// fixed-order column sums of part [n][2][C] (or [n][C] with planes = 1) -> out [planes][C]
-__global__ __launch_bounds__(256) void lm_colsum_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int planes,
-                                                        int C) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= planes * C) return;
-  float s = 0.f;
-#pragma unroll 8
-  for (int i = 0; i < n; ++i) s += part[(size_t)i * planes * C + c];
-  out[c] = s;
+// fixed-order column sums of part [n][planes * C] -> out [planes * C]: a workgroup takes 64 columns, its four waves a
+// quarter of the rows each (in order), and the four partial sums are added in wave order.
+__global__ __launch_bounds__(256) void lm_colsum_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int width) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = blockIdx.x * 64 + lane;
+  const int per = (n + 3) / 4, lo = wave * per, hi = min(n, lo + per);
+  float s0 = 0.f, s1 = 0.f;
+  if (c < width) {
+    int i = lo;
+    for (; i + 1 < hi; i += 2) { s0 += part[(size_t)i * width + c]; s1 += part[(size_t)(i + 1) * width + c]; }
+    if (i < hi) s0 += part[(size_t)i * width + c];
+  }
+  red[wave][lane] = s0 + s1;
+  __syncthreads();
+  if (wave == 0 && c < width) out[c] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
 // ------------------------------------------------------------------------------------------------ bias + relu + dropout
@@ -298,7 +379,7 @@ __global__ __launch_bounds__(256) void lm_bias_relu_bwd_kernel(const float* __re
                                                                float* __restrict__ part, long long rows, int C, int rows_per_blk,
                                                                unsigned key, unsigned thr, float dscale) {
   const long long r0 = (long long)blockIdx.x * rows_per_blk;
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int c = blockIdx.y * 256 + threadIdx.x; c < C; c += 256 * gridDim.y) {
     float s = 0.f;
     for (long long r = r0; r < min(rows, r0 + rows_per_blk); ++r) {
       const long long e = r * C + c;
@@ -390,9 +471,11 @@ extern "C" int smt_lm_attention_fwd(const float* qkv, const int* lens, float* ct
   if (batch <= 0 || len <= 0) return 0;
   SMT_CHECK_ARG(qkv && ctx && lse, "smt_lm_attention_fwd: null pointer");
   SMT_CHECK_ARG(len <= LM_MAXL && heads >= 1, "smt_lm_attention_fwd: len must be <= %d (got %d)", LM_MAXL, len);
-  const size_t lds = 2 * (size_t)len * 33 * sizeof(float);
+  SMT_CHECK_ARG((long long)batch * heads <= 65535, "smt_lm_attention_fwd: batch * heads must be <= 65535");
+  const size_t lds = 2 * (size_t)len * AT_LD * sizeof(float);
   (void)hipFuncSetAttribute((const void*)lm_attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  lm_attn_fwd_kernel<<<batch * heads, std::min(512, (len + 63) / 64 * 64), lds, stream>>>(qkv, lens, ctx, lse, len, heads, causal, drop_key, drop_thresh16, drop_scale);
+  const dim3 grid((len + AT_ROWS - 1) / AT_ROWS, batch * heads);
+  lm_attn_fwd_kernel<<<grid, 256, lds, stream>>>(qkv, lens, ctx, lse, len, heads, causal, drop_key, drop_thresh16, drop_scale);
   SMT_CHECK_LAUNCH("lm_attention_fwd");
   return 0;
 }
@@ -404,11 +487,18 @@ extern "C" int smt_lm_attention_bwd(const float* qkv, const int* lens, const flo
   if (batch <= 0 || len <= 0) return 0;
   SMT_CHECK_ARG(qkv && ctx && lse && dctx && dqkv, "smt_lm_attention_bwd: null pointer");
   SMT_CHECK_ARG(len <= LM_MAXL && heads >= 1, "smt_lm_attention_bwd: len must be <= %d (got %d)", LM_MAXL, len);
-  const size_t lds = (2 * (size_t)len * 33 + 2 * (size_t)len) * sizeof(float);
-  (void)hipFuncSetAttribute((const void*)lm_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  lm_attn_bwd_kernel<<<batch * heads, std::min(512, (len + 63) / 64 * 64), lds, stream>>>(qkv, lens, ctx, lse, dctx, dqkv, len, heads, causal, drop_key,
-                                                          drop_thresh16, drop_scale);
-  SMT_CHECK_LAUNCH("lm_attention_bwd");
+  SMT_CHECK_ARG((long long)batch * heads <= 65535, "smt_lm_attention_bwd: batch * heads must be <= 65535");
+  const dim3 grid((len + AT_ROWS - 1) / AT_ROWS, batch * heads);
+  const size_t lds_q = 2 * (size_t)len * AT_LD * sizeof(float);
+  (void)hipFuncSetAttribute((const void*)lm_attn_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+  lm_attn_dq_kernel<<<grid, 256, lds_q, stream>>>(qkv, lens, ctx, lse, dctx, dqkv, len, heads, causal, drop_key, drop_thresh16,
+                                                 drop_scale);
+  SMT_CHECK_LAUNCH("lm_attention_dq");
+  const size_t lds_k = (2 * (size_t)len * AT_LD + 2 * (size_t)len) * sizeof(float);
+  (void)hipFuncSetAttribute((const void*)lm_attn_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
+  lm_attn_dkv_kernel<<<grid, 256, lds_k, stream>>>(qkv, lens, ctx, lse, dctx, dqkv, len, heads, causal, drop_key, drop_thresh16,
+                                                  drop_scale);
+  SMT_CHECK_LAUNCH("lm_attention_dkv");
   return 0;
 }
 
@@ -427,7 +517,9 @@ extern "C" int smt_lm_add_ln_fwd(const float* x, const float* h, const float* ga
   return 0;
 }
 
-extern "C" size_t smt_lm_add_ln_bwd_workspace_bytes(int64_t rows, int dim) { return (size_t)((rows + 3) / 4) * 2 * dim * sizeof(float); }
+extern "C" size_t smt_lm_add_ln_bwd_workspace_bytes(int64_t rows, int dim) {
+  return (size_t)((rows + LN_RPB - 1) / LN_RPB) * 2 * dim * sizeof(float);
+}
 
 extern "C" int smt_lm_add_ln_bwd(const float* x, const float* h, const float* dy, const float* gamma, const float* stats,
                                  float* dx, float* dh, float* dgamma, float* dbeta, int64_t rows, int dim, uint32_t drop_key,
@@ -443,7 +535,7 @@ extern "C" int smt_lm_add_ln_bwd(const float* x, const float* h, const float* dy
   SMT_CHECK_ARG((x || h) && dy && gamma && stats && workspace, "smt_lm_add_ln_bwd: null pointer");
   SMT_CHECK_ARG(dim % 64 == 0 && dim <= 2048, "smt_lm_add_ln_bwd: dim must be a multiple of 64 up to 2048 (got %d)", dim);
   SMT_CHECK_ARG(workspace_bytes >= smt_lm_add_ln_bwd_workspace_bytes(rows, dim), "smt_lm_add_ln_bwd: workspace too small");
-  const int nblk = (int)((rows + 3) / 4);
+  const int nblk = (int)((rows + LN_RPB - 1) / LN_RPB);
   float* part = (float*)workspace;
   // part [nblk][2][dim]: plane 0 = dgamma, plane 1 = dbeta; dgamma and dbeta must be adjacent for the one reduction
   SMT_CHECK_ARG(dbeta == dgamma + dim, "smt_lm_add_ln_bwd: dbeta must follow dgamma (one [2][dim] buffer)");
@@ -452,7 +544,7 @@ extern "C" int smt_lm_add_ln_bwd(const float* x, const float* h, const float* dy
   LM_LN_DISPATCH(dim, LM_CALL)
 #undef LM_CALL
   SMT_CHECK_LAUNCH("lm_add_ln_bwd");
-  lm_colsum_kernel<<<(2 * dim + 255) / 256, 256, 0, stream>>>(part, dgamma, nblk, 2, dim);
+  lm_colsum_kernel<<<(2 * dim + 63) / 64, 256, 0, stream>>>(part, dgamma, nblk, 2 * dim);
   SMT_CHECK_LAUNCH("lm_colsum");
   return 0;
 }
@@ -478,9 +570,9 @@ extern "C" int smt_lm_bias_relu_bwd(const float* a, const float* da, float* dh, 
   SMT_CHECK_ARG(a && da && dh && workspace, "smt_lm_bias_relu_bwd: null pointer");
   SMT_CHECK_ARG(workspace_bytes >= smt_lm_bias_relu_bwd_workspace_bytes(rows, dim), "smt_lm_bias_relu_bwd: workspace too small");
   const int nblk = (int)((rows + 15) / 16);
-  lm_bias_relu_bwd_kernel<<<nblk, 256, 0, stream>>>(a, da, dh, (float*)workspace, rows, dim, 16, drop_key, drop_thresh16, drop_scale);
+  lm_bias_relu_bwd_kernel<<<dim3(nblk, (dim + 255) / 256), 256, 0, stream>>>(a, da, dh, (float*)workspace, rows, dim, 16, drop_key, drop_thresh16, drop_scale);
   SMT_CHECK_LAUNCH("lm_bias_relu_bwd");
-  lm_colsum_kernel<<<(dim + 255) / 256, 256, 0, stream>>>((const float*)workspace, dbias, nblk, 1, dim);
+  lm_colsum_kernel<<<(dim + 63) / 64, 256, 0, stream>>>((const float*)workspace, dbias, nblk, dim);
   SMT_CHECK_LAUNCH("lm_colsum");
   return 0;
 }

@@ -157,7 +157,8 @@ class TransformerLM(TokenToWaveformModel):
     def forward(self, x, x_lengths, y, y_lengths, speaker=None):
         b, l = x.shape
         lens = x_lengths.to(device=x.device, dtype=torch.int32)
-        self._drop_seed += 1
+        if self.training:
+            self._drop_seed += 1                                # one fresh set of dropout masks per training step
         xh = self.logits(x, lens, causal=True)
         # next-token targets (transformer_lm.py:121-126): position t predicts x[t + 1]; pads / specials are not scored
         nxt = x[:, 1:]

@@ -111,8 +111,8 @@ def val_epoch(*, epoch, config, model, ema, val_dataloader, writer, device):
             ys += list(loss_dict["y"][:4 - len(ys)]); yhs += list(loss_dict["yh"][:4 - len(yhs)])
     ema.swap()
     log_stats(epoch, writer, losses, metrics, prefix="val")
-    from models.base import WaveformReconstructionModel
-    if isinstance(model, WaveformReconstructionModel) and ys:               # train.py:296-299
+    from models.base import TokenToWaveformModel, WaveformReconstructionModel
+    if isinstance(model, (TokenToWaveformModel, WaveformReconstructionModel)) and ys:     # train.py:296-299
         n = min(len(ys), len(yhs))
         t = min(min(v.shape[-1] for v in ys[:n]), min(v.shape[-1] for v in yhs[:n]))
         save_audio_and_computed_spect(config, epoch, writer, torch.stack([v[:t] for v in ys[:n]]),

@@ -297,3 +297,44 @@ def test_full_size_train_step_matches_the_oracle(tmp_path):
     assert abs(float(metrics["accuracy"]) - float(acc)) < 2e-3                       # a near-tie may flip one of ~2000 rows
     worst = max((rel(prm.grad, pc[name].grad), name) for name, prm in model.named_parameters() if not name.startswith("vqvae."))
     assert worst[0] < 5e-3, worst
+
+
+def test_train_py_end_to_end_on_generated_codes(tmp_path, monkeypatch):
+    """The reference's pipeline for this model (scripts/train_transformer_lm.sh): VQ-VAE checkpoint ->
+    scripts/generate_vq_dataset.py -> `train.py --model transformer_lm --dataset vqlatent`; two epochs, validation with
+    reconstructed audio, checkpoint written and resumed."""
+    import train
+    from scripts import generate_vq_dataset as G
+    from utils import config as C
+    log_vq, _ = _vqvae_run(tmp_path, l_bins=16)
+    dump_dir = str(tmp_path / "VQ-Latent")
+    ds_cfg = C.load(os.path.join(log_vq, "config.yaml"))
+    ds_cfg.dataset.update(C.create(dict(num_clips=6, ragged=True)))
+    C.save(ds_cfg, os.path.join(log_vq, "config.yaml"))
+    G.main(["--log_dir", log_vq, "--ckpt_num", "3", "--dump_dir", dump_dir, "--batch_size", "3", "--n_processes", "1", "--n_workers", "0"])
+    monkeypatch.chdir(PKG)
+    C.save(_lm_config(log_vq, **SMALL, ), "configs/models/_test_lm.yaml")
+    vql = C.load("configs/datasets/vqlatent.yaml")
+    vql.dataset.update(C.create(dict(dataset_path=dump_dir, segment_length=24)))
+    C.save(vql, "configs/datasets/_test_vql.yaml")
+    try:
+        log_dir = str(tmp_path / "run")
+        argv = ["--model", "_test_lm", "--dataset", "_test_vql", "--batch_size", "3", "--num_workers", "0", "--total_epochs", "2",
+                "--log_every_n_steps", "1", "--ckpt_every_n_steps", "2", "--eval_every_n_epochs", "1", "--log_dir", log_dir,
+                "--n_gpus", "1", "--run_sanity_val_epoch"]
+        train.main(argv)
+        last = torch.load(os.path.join(log_dir, "ckpts", "ckpt.last.pt"), weights_only=True)
+        assert last["step"] == 4 and "transformer.layers.1.self_attn.in_proj_weight" in last["model"]
+        assert "vqvae.bottleneck.k" in last["model"] and last["extra"]["drop_seed"] == 4
+        import json
+        import wave
+        scal = os.path.join(log_dir, "scalars.jsonl")
+        if os.path.exists(scal):
+            tags = {json.loads(line)["tag"] for line in open(scal)}
+            assert {"loss/train_loss", "metrics/train_accuracy", "loss/val_loss"} <= tags
+        with wave.open(os.path.join(log_dir, "audio", "val_audio_2_pred.wav")) as w:
+            assert w.getframerate() == 22050 and w.getnframes() >= 24 * 128
+        train.main(argv + ["--load_ckpt", os.path.join(log_dir, "ckpts", "ckpt.last.pt")])
+    finally:
+        os.remove("configs/models/_test_lm.yaml")
+        os.remove("configs/datasets/_test_vql.yaml")

@@ -333,22 +333,24 @@ int smt_lm_embed_bwd(const int64_t* tokens, const float* dout, float* demb, int 
  *   ctx [batch, len, heads*32] = dropout(softmax(q k^T / sqrt(32) + masks)) v;   lse [batch, heads, len] (saved for bwd)
  * key j is visible to query i iff (j <= i or causal == 0) and j < lens[b] -- causal = 0 is what `sample` runs
  * (mask=None, :142); dropout index ((b*heads + h)*len + i)*len + j.
- * bwd writes dqkv [batch, len, 3*heads*32] (every element). */
+ * bwd writes dqkv [batch, len, 3*heads*32] (every element); delta [batch, heads, len] is scratch it fills and reads. */
 int smt_lm_attention_fwd(const float* qkv, const int* lens, float* ctx, float* lse, int batch, int len, int heads,
                          int causal, uint32_t drop_key, uint32_t drop_thresh16, float drop_scale, smt_stream_t stream);
 int smt_lm_attention_bwd(const float* qkv, const int* lens, const float* ctx, const float* lse, const float* dctx,
-                         float* dqkv, int batch, int len, int heads, int causal, uint32_t drop_key,
+                         float* dqkv, float* delta, int batch, int len, int heads, int causal, uint32_t drop_key,
                          uint32_t drop_thresh16, float drop_scale, smt_stream_t stream);
 
-/* y = LayerNorm(x + dropout(h)) * gamma + beta over the last dim (TransformerEncoderLayer, norm_first = False; with
- * h = NULL the plain final LayerNorm of the encoder, :63-66); stats [rows, 2] = (mean, rstd).  dim = 64 * {1,2,4,8,12,
- * 16,32}.  bwd: dx / dh may be NULL (not wanted); dgamma [2, dim] holds dgamma then dbeta (dbeta == dgamma + dim). */
-int smt_lm_add_ln_fwd(const float* x, const float* h, const float* gamma, const float* beta, float* y, float* stats,
-                      int64_t rows, int dim, float eps, uint32_t drop_key, uint32_t drop_thresh16, float drop_scale,
-                      smt_stream_t stream);
+/* y = LayerNorm(x + dropout(h + h_bias)) * gamma + beta over the last dim (TransformerEncoderLayer, norm_first = False):
+ * h is the bias-free output of out_proj / linear2 and h_bias [dim] that projection's bias (NULL = none), so that the
+ * bias gradient falls out of this kernel's backward instead of a separate reduction; with h = NULL the plain final
+ * LayerNorm of the encoder (:63-66).  stats [rows, 2] = (mean, rstd).  dim = 64 * {1,2,4,8,12,16,32}.
+ * bwd: dx / dh may be NULL (not wanted); dparams [3, dim] = dgamma, dbeta, dh_bias (column sums of dh). */
+int smt_lm_add_ln_fwd(const float* x, const float* h, const float* h_bias, const float* gamma, const float* beta, float* y,
+                      float* stats, int64_t rows, int dim, float eps, uint32_t drop_key, uint32_t drop_thresh16,
+                      float drop_scale, smt_stream_t stream);
 size_t smt_lm_add_ln_bwd_workspace_bytes(int64_t rows, int dim);
-int smt_lm_add_ln_bwd(const float* x, const float* h, const float* dy, const float* gamma, const float* stats, float* dx,
-                      float* dh, float* dgamma, float* dbeta, int64_t rows, int dim, uint32_t drop_key,
+int smt_lm_add_ln_bwd(const float* x, const float* h, const float* h_bias, const float* dy, const float* gamma,
+                      const float* stats, float* dx, float* dh, float* dparams, int64_t rows, int dim, uint32_t drop_key,
                       uint32_t drop_thresh16, float drop_scale, void* workspace, size_t workspace_bytes,
                       smt_stream_t stream);
 

@@ -50,217 +50,246 @@ __global__ __launch_bounds__(256) void lm_embed_bwd_kernel(const long long* __re
 // ------------------------------------------------------------------------------------------------ attention
 // qkv [B, L, 3 d] (q | k | v, heads side by side inside each), ctx [B, L, d], lse [B, H, L] (log-sum-exp of the scaled,
 // masked scores).  Key j is visible to query i iff (j <= i or not causal) and j < lens[b].  Attention-weight dropout:
-// element index ((b H + h) L + i) L + j.
-//
-// Work split (all three kernels): a workgroup owns 64 consecutive rows of one (batch, head) -- queries in the forward and
-// the dq kernel, keys in the dk/dv kernel -- and AT_G = 4 adjacent lanes share a row, lane g walking the opposite index
-// j = g, g + 4, ...; the four partial results meet in two xor-shuffles.  The opposite side (K, V or scaled Q, dctx) sits in
-// LDS at a pitch of 36 floats: the four rows a lane group reads at once fall into disjoint bank groups, and the 16 groups
-// of a wave read the same four rows (broadcast).  B H ceil(L / 64) workgroups (640 at the reference's 8 x 16 x 258) of four
-// waves fill the chip; the causal triangle makes later tiles longer, so tiles are issued longest first.
-constexpr int LM_DH = 32, LM_MAXL = 512, AT_G = 4, AT_ROWS = 64, AT_LD = 36;
+// element index ((b H + h) L + i) L + j.  Head dim 32.  (Two earlier generations of these kernels ran on the VALU: K / V
+// staged in LDS with four lanes per query row was bound by the 128 B/clk LDS pipe -- every lane pulling the same 256 bytes
+// per key -- at 48 / 50 / 58 us for forward / dq / dkv at 8 x 16 x 258; broadcasting the rows through scalar loads instead
+// was bound by the scalar cache's miss latency, 70 / 50 / 63 us.)
+constexpr int LM_DH = 32, LM_MAXL = 512;
 
-// stage `n` rows of width 32 from global (row pitch `pitch` floats) into LDS rows of AT_LD floats, times `mul`
-__device__ __forceinline__ void at_stage(float* dst, const float* __restrict__ src, size_t pitch, int n, float mul) {
-  for (int f = threadIdx.x; f < n * 8; f += 256) {
-    const int j = f >> 3, c4 = f & 7;
-    f32x4 v = *(const f32x4*)(src + (size_t)j * pitch + c4 * 4);
-    *(f32x4*)(dst + j * AT_LD + c4 * 4) = v * mul;
-  }
-}
-__device__ __forceinline__ float at_dot(const float* __restrict__ row, const float (&q)[LM_DH]) {
-  float s0 = 0.f, s1 = 0.f;
+// The attention kernels run on the f32-input matrix pipe (v_mfma_f32_32x32x2_f32: exact f32 products and sums at the
+// VALU's FLOP rate, but one operand register per 32 FMAs instead of one LDS read per FMA).  A workgroup owns 32 rows of
+// one (batch, head) -- queries in the forward and the dq kernel, keys in the dk/dv kernel -- and its four waves take
+// every fourth 32-row block of the opposite index; their partial results meet in LDS at the end.  Everything is
+// transposed so that the owned row is the accumulator COLUMN (= the lane): S^T = K Q^T, softmax statistics per lane,
+// ctx^T += V^T P^T with P^T taken straight from the accumulator registers (its key order, rows (i & 3) + 8 (i >> 2) +
+// 4 (lane >> 5), is matched by the order V's rows are fetched in).  Operands come straight from global memory
+// (L2-resident: a head's K and V are 66 KB): no LDS in the loops, no barriers but the final merge; with up to four waves per
+// SIMD the loads of one wave hide behind the MFMAs of the others (register double-buffering them measured slower).  Two fragment shapes:
+// "row" = 16 consecutive channels [16 hh, 16 hh + 16) of row `col` (the contraction runs over channels), "column" =
+// channel `col` of the 16 rows at_acc_row(t, hh) (the contraction runs over rows).  Offsets are 32-bit element counts
+// from a wave-uniform base (64-bit per-lane address arithmetic cost more than the MFMAs in a first version).
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+constexpr int AT_W = 4;
+__device__ __forceinline__ int at_acc_row(int i, int hh) { return (i & 3) + 8 * (i >> 2) + 4 * hh; }
+__device__ __forceinline__ void at_row_frag(float (&r)[16], const float* __restrict__ mat, unsigned pitch, int row, int last, int hh,
+                                            float mul) {
+  const float* src = mat + ((unsigned)min(row, last) * pitch + 16u * hh);
 #pragma unroll
-  for (int c = 0; c < LM_DH; c += 8) {
-    const f32x4 a = *(const f32x4*)(row + c), b = *(const f32x4*)(row + c + 4);
-    s0 = fmaf(q[c], a.x, s0); s0 = fmaf(q[c + 1], a.y, s0); s0 = fmaf(q[c + 2], a.z, s0); s0 = fmaf(q[c + 3], a.w, s0);
-    s1 = fmaf(q[c + 4], b.x, s1); s1 = fmaf(q[c + 5], b.y, s1); s1 = fmaf(q[c + 6], b.z, s1); s1 = fmaf(q[c + 7], b.w, s1);
-  }
-  return s0 + s1;
-}
-__device__ __forceinline__ void at_axpy(float (&acc)[LM_DH], float a, const float* __restrict__ row) {
-#pragma unroll
-  for (int c = 0; c < LM_DH; c += 4) {
-    const f32x4 v = *(const f32x4*)(row + c);
-    acc[c] = fmaf(a, v.x, acc[c]); acc[c + 1] = fmaf(a, v.y, acc[c + 1]);
-    acc[c + 2] = fmaf(a, v.z, acc[c + 2]); acc[c + 3] = fmaf(a, v.w, acc[c + 3]);
-  }
-}
-__device__ __forceinline__ void at_load_row(float (&r)[LM_DH], const float* __restrict__ src, float mul) {
-#pragma unroll
-  for (int c = 0; c < LM_DH; c += 4) {
+  for (int c = 0; c < 16; c += 4) {
     const f32x4 v = *(const f32x4*)(src + c);
     r[c] = v.x * mul; r[c + 1] = v.y * mul; r[c + 2] = v.z * mul; r[c + 3] = v.w * mul;
   }
 }
-// lane g of the group keeps channels [8 g, 8 g + 8) of the group sum of acc
-__device__ __forceinline__ void at_group_sum_store(float (&acc)[LM_DH], int g, float mul, float* __restrict__ dst) {
+__device__ __forceinline__ void at_col_frag(float (&r)[16], const float* __restrict__ mat, unsigned pitch, int row0, int last, int col,
+                                            int hh) {
+  const int first = row0 + 4 * hh;
+  const unsigned base_off = (unsigned)first * pitch + col, last_off = (unsigned)last * pitch + col;
 #pragma unroll
-  for (int c = 0; c < LM_DH; ++c) {
-    acc[c] += __shfl_xor(acc[c], 1, 64);
-    acc[c] += __shfl_xor(acc[c], 2, 64);
+  for (int t = 0; t < 16; ++t) {
+    const int k = (t & 3) + 8 * (t >> 2);                     // compile time: k * pitch is a scalar
+    r[t] = mat[first + k <= last ? base_off + (unsigned)k * pitch : last_off];
   }
-  f32x4 o0, o1;
+}
+__device__ __forceinline__ f32x16v at_mfma16(const float (&a)[16], const float (&b)[16], f32x16v c) {
 #pragma unroll
-  for (int gg = 0; gg < AT_G; ++gg)
-    if (g == gg) {
-      o0 = f32x4{acc[8 * gg], acc[8 * gg + 1], acc[8 * gg + 2], acc[8 * gg + 3]} * mul;
-      o1 = f32x4{acc[8 * gg + 4], acc[8 * gg + 5], acc[8 * gg + 6], acc[8 * gg + 7]} * mul;
-    }
-  *(f32x4*)(dst + 8 * g) = o0;
-  *(f32x4*)(dst + 8 * g + 4) = o1;
+  for (int t = 0; t < 16; ++t) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], c, 0, 0, 0);
+  return c;
+}
+__device__ __forceinline__ f32x16v at_zero16() {
+  f32x16v z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+// Sum the four waves' transposed accumulators (each scaled by its own `scale`) through LDS red [4][16][64]; wave w then
+// stores channel group w -- channels 8 w + 4 hh + {0..3} -- of the row this lane's column stands for, times mul.
+__device__ __forceinline__ void at_merge_store(float* red, const f32x16v& o, float scale, int w, int lane, int hh, float mul, bool live,
+                                               float* __restrict__ dst) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) red[(w * 16 + i) * 64 + lane] = o[i] * scale;
+  __syncthreads();
+  f32x4 out;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = 4 * w + k;
+    out[k] = (((red[i * 64 + lane] + red[(16 + i) * 64 + lane]) + red[(32 + i) * 64 + lane]) + red[(48 + i) * 64 + lane]) * mul;
+  }
+  if (live) *(f32x4*)(dst + 8 * w + 4 * hh) = out;
+  __syncthreads();
 }
 
 __global__ __launch_bounds__(256) void lm_attn_fwd_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
                                                           float* __restrict__ ctx, float* __restrict__ lse, int L, int H,
                                                           int causal, unsigned key, unsigned thr, float dscale) {
-  extern __shared__ float sm[];                               // K [nk][36] | V [nk][36]
-  const int tile = gridDim.x - 1 - blockIdx.x;                // longest (last) tiles first
+  __shared__ float red[AT_W * 16 * 64];
+  __shared__ float red_m[AT_W][64], red_z[AT_W][64];
+  const int qb = gridDim.x - 1 - blockIdx.x;                  // longest (last) query blocks first
   const int b = blockIdx.y / H, h = blockIdx.y % H, d = H * LM_DH;
-  const float* base = qkv + (size_t)b * L * 3 * d + h * LM_DH;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, col = lane & 31, hh = lane >> 5;
+  const unsigned pitch = 3u * d;
+  const float* qm = qkv + (size_t)b * L * pitch + h * LM_DH;
+  const float* km = qm + d;
+  const float* vm = qm + 2 * d;
   const int len = lens ? max(0, min(lens[b], L)) : L;
-  const int nk = causal ? min(len, min(L, (tile + 1) * AT_ROWS)) : len;   // keys any row of this tile can see
-  float* ks = sm;
-  float* vs = sm + (size_t)nk * AT_LD;
-  at_stage(ks, base + d, 3 * (size_t)d, nk, 1.f);
-  at_stage(vs, base + 2 * d, 3 * (size_t)d, nk, 1.f);
-  __syncthreads();
-  const int g = threadIdx.x & (AT_G - 1), i = tile * AT_ROWS + (threadIdx.x >> 2);
-  if (i >= L) return;                                         // whole lane groups leave together
-  float q[LM_DH], acc[LM_DH];
-  at_load_row(q, base + (size_t)i * 3 * d, rsqrtf((float)LM_DH));
-#pragma unroll
-  for (int c = 0; c < LM_DH; ++c) acc[c] = 0.f;
+  const int q0 = qb * 32, qi = q0 + col, qc = min(qi, L - 1);
+  const int kend = causal ? min(len, min(L, q0 + 32)) : len;  // keys any query of this block can see
+  float qf[16];
+  at_row_frag(qf, qm, pitch, qi, L - 1, hh, rsqrtf((float)LM_DH));
+  f32x16v o = at_zero16();
   float m = -INFINITY, z = 0.f;
-  const int jn = causal ? min(i + 1, len) : len;
-  const unsigned long long e0 = (((unsigned long long)b * H + h) * L + i) * L;
-  for (int j = g; j < jn; j += AT_G) {
-    const float s = at_dot(ks + j * AT_LD, q);
-    if (s > m) {                                              // new running maximum: rescale what is accumulated
-      const float corr = __expf(m - s);
-      z *= corr;
+  const unsigned long long e0 = (((unsigned long long)b * H + h) * L + qc) * L;
+  for (int k0 = 32 * w; k0 < kend; k0 += 32 * AT_W) {
+    float kf[16], vf[16];
+    at_row_frag(kf, km, pitch, k0 + col, L - 1, hh, 1.f);
+    at_col_frag(vf, vm, pitch, k0, L - 1, col, hh);
+    f32x16v st = at_mfma16(kf, qf, at_zero16());
+    float mloc = -INFINITY;
 #pragma unroll
-      for (int c = 0; c < LM_DH; ++c) acc[c] *= corr;
-      m = s;
+    for (int i = 0; i < 16; ++i) {
+      const int kj = k0 + at_acc_row(i, hh);
+      st[i] = (kj < kend && (!causal || kj <= qi)) ? st[i] : -INFINITY;
+      mloc = fmaxf(mloc, st[i]);
     }
-    const float p = __expf(s - m);
-    z += p;
-    at_axpy(acc, p * lm_keep(e0 + j, key, thr, dscale), vs + j * AT_LD);
-  }
-  // merge the four partial softmaxes of the row
-  float mm = fmaxf(m, __shfl_xor(m, 1, 64));
-  mm = fmaxf(mm, __shfl_xor(mm, 2, 64));
-  const float sc = (m == -INFINITY) ? 0.f : __expf(m - mm);
-  z *= sc;
-  z += __shfl_xor(z, 1, 64);
-  z += __shfl_xor(z, 2, 64);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float mn = fmaxf(m, mloc), ms = (mn == -INFINITY) ? 0.f : mn;
+    const float corr = __expf(m - ms);                        // m = -inf: 0
+    z *= corr;
 #pragma unroll
-  for (int c = 0; c < LM_DH; ++c) acc[c] *= sc;
-  at_group_sum_store(acc, g, jn > 0 ? 1.f / z : 0.f, ctx + ((size_t)b * L + i) * d + h * LM_DH);
-  if (g == 0) lse[((size_t)b * H + h) * L + i] = jn > 0 ? mm + __logf(z) : 0.f;
+    for (int i = 0; i < 16; ++i) o[i] *= corr;
+    m = mn;
+    float pk[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float p = __expf(st[i] - ms);                     // masked: exp(-inf) = 0
+      z += p;
+      pk[i] = p * lm_keep(e0 + k0 + at_acc_row(i, hh), key, thr, dscale);
+    }
+    o = at_mfma16(vf, pk, o);
+  }
+  // merge the four waves' partial softmaxes (m is per query = the same in both lane halves; z is a per-half partial)
+  red_m[w][lane] = m; red_z[w][lane] = z;
+  __syncthreads();
+  const float mm = fmaxf(fmaxf(red_m[0][lane], red_m[1][lane]), fmaxf(red_m[2][lane], red_m[3][lane]));
+  float zz = 0.f;
+#pragma unroll
+  for (int k = 0; k < AT_W; ++k) zz += red_m[k][lane] == -INFINITY ? 0.f : red_z[k][lane] * __expf(red_m[k][lane] - mm);
+  zz += __shfl_xor(zz, 32, 64);
+  const bool any = mm != -INFINITY;                           // at least one visible key
+  at_merge_store(red, o, (m == -INFINITY) ? 0.f : __expf(m - mm), w, lane, hh, any ? 1.f / zz : 0.f, qi < L,
+                 ctx + ((size_t)b * L + qc) * d + h * LM_DH);
+  if (w == 0 && hh == 0 && qi < L) lse[((size_t)b * H + h) * L + qi] = any ? mm + __logf(zz) : 0.f;
 }
 
 // Backward: P_ij = exp(s_ij - lse_i); dPd_ij = dctx_i . v_j; delta_i = sum_j P_ij keep_ij dPd_ij = dctx_i . ctx_i;
 // dS_ij = P_ij (keep_ij dPd_ij - delta_i); dq_i = sum_j dS_ij k_j / sqrt(dh); dk_j = sum_i dS_ij q_i / sqrt(dh);
-// dv_j = sum_i P_ij keep_ij dctx_i.  dq: query tiles against K, V in LDS.
+// dv_j = sum_i P_ij keep_ij dctx_i.
+// dq: 32 queries per workgroup (the accumulator column): S^T = K Q^T, dPd^T = V dctx^T, dq^T += K^T dS^T; leaves delta.
 __global__ __launch_bounds__(256) void lm_attn_dq_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
                                                          const float* __restrict__ ctx, const float* __restrict__ lse,
-                                                         const float* __restrict__ dctx, float* __restrict__ dqkv, int L, int H,
-                                                         int causal, unsigned key, unsigned thr, float dscale) {
-  extern __shared__ float sm[];
-  const int tile = gridDim.x - 1 - blockIdx.x;
+                                                         const float* __restrict__ dctx, float* __restrict__ dqkv,
+                                                         float* __restrict__ delta, int L, int H, int causal, unsigned key,
+                                                         unsigned thr, float dscale) {
+  __shared__ float red[AT_W * 16 * 64];
+  const int qb = gridDim.x - 1 - blockIdx.x;
   const int b = blockIdx.y / H, h = blockIdx.y % H, d = H * LM_DH;
-  const float* base = qkv + (size_t)b * L * 3 * d + h * LM_DH;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, col = lane & 31, hh = lane >> 5;
+  const unsigned pitch = 3u * d;
+  const float* qm = qkv + (size_t)b * L * pitch + h * LM_DH;
+  const float* km = qm + d;
+  const float* vm = qm + 2 * d;
   const int len = lens ? max(0, min(lens[b], L)) : L;
-  const int nk = causal ? min(len, min(L, (tile + 1) * AT_ROWS)) : len;
-  float* ks = sm;
-  float* vs = sm + (size_t)nk * AT_LD;
-  at_stage(ks, base + d, 3 * (size_t)d, nk, 1.f);
-  at_stage(vs, base + 2 * d, 3 * (size_t)d, nk, 1.f);
-  __syncthreads();
-  const int g = threadIdx.x & (AT_G - 1), i = tile * AT_ROWS + (threadIdx.x >> 2);
-  if (i >= L) return;
+  const int q0 = qb * 32, qi = q0 + col, qc = min(qi, L - 1);
+  const int kend = causal ? min(len, min(L, q0 + 32)) : len;
   const float sc = rsqrtf((float)LM_DH);
-  float q[LM_DH], go[LM_DH], dq[LM_DH];
-  at_load_row(q, base + (size_t)i * 3 * d, sc);
-  at_load_row(go, dctx + ((size_t)b * L + i) * d + h * LM_DH, 1.f);
-  const float dl = at_dot(ctx + ((size_t)b * L + i) * d + h * LM_DH, go);
+  float qf[16], gf[16];
+  at_row_frag(qf, qm, pitch, qi, L - 1, hh, sc);
+  at_row_frag(gf, dctx + (size_t)b * L * d + h * LM_DH, d, qi, L - 1, hh, 1.f);
+  float dl = 0.f;
+  {
+    float cf[16];
+    at_row_frag(cf, ctx + (size_t)b * L * d + h * LM_DH, d, qi, L - 1, hh, 1.f);
 #pragma unroll
-  for (int c = 0; c < LM_DH; ++c) dq[c] = 0.f;
-  const float li = lse[((size_t)b * H + h) * L + i];
-  const int jn = causal ? min(i + 1, len) : len;
-  const unsigned long long e0 = (((unsigned long long)b * H + h) * L + i) * L;
-  for (int j = g; j < jn; j += AT_G) {
-    const float p = __expf(at_dot(ks + j * AT_LD, q) - li);
-    const float dp = at_dot(vs + j * AT_LD, go);
-    at_axpy(dq, p * (lm_keep(e0 + j, key, thr, dscale) * dp - dl), ks + j * AT_LD);
+    for (int t = 0; t < 16; ++t) dl = fmaf(gf[t], cf[t], dl);
+    dl += __shfl_xor(dl, 32, 64);
   }
-  at_group_sum_store(dq, g, sc, dqkv + ((size_t)b * L + i) * 3 * d + h * LM_DH);
+  if (w == 0 && hh == 0 && qi < L) delta[((size_t)b * H + h) * L + qi] = dl;
+  const float li = lse[((size_t)b * H + h) * L + qc];
+  const unsigned long long e0 = (((unsigned long long)b * H + h) * L + qc) * L;
+  f32x16v dq = at_zero16();
+  for (int k0 = 32 * w; k0 < kend; k0 += 32 * AT_W) {
+    float kf[16], vf[16], kc[16];
+    at_row_frag(kf, km, pitch, k0 + col, L - 1, hh, 1.f);
+    at_row_frag(vf, vm, pitch, k0 + col, L - 1, hh, 1.f);
+    at_col_frag(kc, km, pitch, k0, L - 1, col, hh);
+    const f32x16v st = at_mfma16(kf, qf, at_zero16());
+    const f32x16v dp = at_mfma16(vf, gf, at_zero16());
+    float ds[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int kj = k0 + at_acc_row(i, hh);
+      const float p = (kj < kend && (!causal || kj <= qi)) ? __expf(st[i] - li) : 0.f;
+      ds[i] = p * (lm_keep(e0 + kj, key, thr, dscale) * dp[i] - dl);
+    }
+    dq = at_mfma16(kc, ds, dq);
+  }
+  at_merge_store(red, dq, 1.f, w, lane, hh, sc, qi < L, dqkv + ((size_t)b * L + qc) * pitch + h * LM_DH);
 }
 
-// dk, dv: key tiles against the scaled queries and dctx (plus lse, delta per query) in LDS.
+// dk, dv: 32 keys per workgroup (the accumulator column): S = Q K^T and dPd = dctx V^T with the queries in the accumulator
+// rows, then dv^T += dctx^T (P keep), dk^T += Q^T dS.  lse and delta of the 16 query rows a lane holds are loaded per block.
 __global__ __launch_bounds__(256) void lm_attn_dkv_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
-                                                          const float* __restrict__ ctx, const float* __restrict__ lse,
-                                                          const float* __restrict__ dctx, float* __restrict__ dqkv, int L, int H,
-                                                          int causal, unsigned key, unsigned thr, float dscale) {
-  extern __shared__ float sm[];                               // Q [nq][36] | dO [nq][36] | lse [nq] | delta [nq]
-  const int tile = blockIdx.x;                                // first key tiles see the most queries: already longest first
+                                                          const float* __restrict__ lse, const float* __restrict__ dctx,
+                                                          const float* __restrict__ delta, float* __restrict__ dqkv, int L,
+                                                          int H, int causal, unsigned key, unsigned thr, float dscale) {
+  __shared__ float red[AT_W * 16 * 64];
+  const int kb = blockIdx.x;                                  // first key blocks see the most queries: longest first
   const int b = blockIdx.y / H, h = blockIdx.y % H, d = H * LM_DH;
-  const float* base = qkv + (size_t)b * L * 3 * d + h * LM_DH;
-  float* dbase = dqkv + (size_t)b * L * 3 * d + h * LM_DH;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, col = lane & 31, hh = lane >> 5;
+  const unsigned pitch = 3u * d;
+  const float* qm = qkv + (size_t)b * L * pitch + h * LM_DH;
+  const float* gm = dctx + (size_t)b * L * d + h * LM_DH;
+  const float* lrow = lse + ((size_t)b * H + h) * L;
+  const float* drow = delta + ((size_t)b * H + h) * L;
   const int len = lens ? max(0, min(lens[b], L)) : L;
-  const int i0 = causal ? tile * AT_ROWS : 0, nq = L - i0;    // queries [i0, L) can see keys of this tile
-  const int g = threadIdx.x & (AT_G - 1), j = tile * AT_ROWS + (threadIdx.x >> 2);
-  float* qs = sm;
-  float* gs = qs + (size_t)nq * AT_LD;
-  float* ls = gs + (size_t)nq * AT_LD;
-  float* delta = ls + nq;
-  const bool tile_live = tile * AT_ROWS < len;                // uniform: any visible key in this tile at all?
-  if (tile_live) {
-    const float sc = rsqrtf((float)LM_DH);
-    at_stage(qs, base + (size_t)i0 * 3 * d, 3 * (size_t)d, nq, sc);
-    const float* gsrc = dctx + ((size_t)b * L + i0) * d + h * LM_DH;
-    const float* csrc = ctx + ((size_t)b * L + i0) * d + h * LM_DH;
-    for (int f = threadIdx.x; f < ((nq * 8 + 63) & ~63); f += 256) {      // whole waves: the shuffles below need all 8 lanes
-      const int r = f >> 3, c4 = f & 7;
-      float part = 0.f;
-      if (r < nq) {
-        const f32x4 gv = *(const f32x4*)(gsrc + (size_t)r * d + c4 * 4), cv = *(const f32x4*)(csrc + (size_t)r * d + c4 * 4);
-        *(f32x4*)(gs + r * AT_LD + c4 * 4) = gv;
-        part = gv.x * cv.x + gv.y * cv.y + gv.z * cv.z + gv.w * cv.w;
-      }
-      part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);
-      if (r < nq && c4 == 0) { delta[r] = part; ls[r] = lse[((size_t)b * H + h) * L + i0 + r]; }
-    }
-  }
-  __syncthreads();
-  if (j >= L) return;
-  float dk[LM_DH], dv[LM_DH];
+  const int kj = kb * 32 + col, kc = min(kj, L - 1);
+  const float sc = rsqrtf((float)LM_DH);
+  float kf[16], vf[16];
+  at_row_frag(kf, qm + d, pitch, kj, L - 1, hh, sc);           // 1/sqrt(dh) folded into the key
+  at_row_frag(vf, qm + 2 * d, pitch, kj, L - 1, hh, 1.f);
+  f32x16v dk = at_zero16(), dv = at_zero16();
+  const unsigned long long e0 = ((unsigned long long)b * H + h) * L;
+  if (kb * 32 < len) {                                        // uniform: any visible key in this block at all?
+    for (int q0 = (causal ? kb * 32 : 0) + 32 * w; q0 < L; q0 += 32 * AT_W) {
+      float qa[16], ga[16], qc[16], gc[16];
+      at_row_frag(qa, qm, pitch, q0 + col, L - 1, hh, 1.f);
+      at_row_frag(ga, gm, d, q0 + col, L - 1, hh, 1.f);
+      at_col_frag(qc, qm, pitch, q0, L - 1, col, hh);
+      at_col_frag(gc, gm, d, q0, L - 1, col, hh);
+      const f32x16v st = at_mfma16(qa, kf, at_zero16());
+      const f32x16v dp = at_mfma16(ga, vf, at_zero16());
+      float pk[16], ds[16];
 #pragma unroll
-  for (int c = 0; c < LM_DH; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
-  if (j < len) {
-    float kk[LM_DH], vv[LM_DH];
-    at_load_row(kk, base + (size_t)j * 3 * d + d, 1.f);
-    at_load_row(vv, base + (size_t)j * 3 * d + 2 * d, 1.f);
-    const int r0 = causal ? (j - i0) : 0;                     // first query row (relative to i0) that sees key j
-    for (int r = (r0 & ~(AT_G - 1)) + g; r < nq; r += AT_G) {
-      if (r < r0) continue;
-      const float p = __expf(at_dot(qs + r * AT_LD, kk) - ls[r]);
-      const float kp = lm_keep((((unsigned long long)b * H + h) * L + i0 + r) * L + j, key, thr, dscale);
-      const float dp = at_dot(gs + r * AT_LD, vv);
-      at_axpy(dk, p * (kp * dp - delta[r]), qs + r * AT_LD);   // q in LDS already carries 1/sqrt(dh)
-      at_axpy(dv, p * kp, gs + r * AT_LD);
+      for (int i = 0; i < 16; ++i) {
+        const int qr = q0 + at_acc_row(i, hh), qrc = min(qr, L - 1);
+        const float p = (qr < L && kj < len && (!causal || kj <= qr)) ? __expf(st[i] - lrow[qrc]) : 0.f;
+        pk[i] = p * lm_keep((e0 + qrc) * L + kc, key, thr, dscale);
+        ds[i] = pk[i] * dp[i] - p * drow[qrc];
+      }
+      dv = at_mfma16(gc, pk, dv);
+      dk = at_mfma16(qc, ds, dk);
     }
   }
-  at_group_sum_store(dk, g, 1.f, dbase + (size_t)j * 3 * d + d);
-  at_group_sum_store(dv, g, 1.f, dbase + (size_t)j * 3 * d + 2 * d);
+  float* dst = dqkv + ((size_t)b * L + kc) * pitch + h * LM_DH;
+  at_merge_store(red, dk, 1.f, w, lane, hh, sc, kj < L, dst + d);
+  at_merge_store(red, dv, 1.f, w, lane, hh, 1.f, kj < L, dst + 2 * d);
 }
 
 // ------------------------------------------------------------------------------------------------ add + LayerNorm
-// y = LN(x + dropout(h)) * gamma + beta; one wave per row, PER = C / 64 elements per lane in registers;
+// y = LN(x + dropout(h + hbias)) * gamma + beta; one wave per row, PER = C / 64 elements per lane in registers;
 // stats [rows][2] = (mean, rstd).
 template <int PER>
 __global__ __launch_bounds__(256) void lm_add_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ hh,
+                                                            const float* __restrict__ hbias,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ y, float* __restrict__ stats, long long rows,
                                                             float eps, unsigned key, unsigned thr, float dscale) {
@@ -273,7 +302,8 @@ __global__ __launch_bounds__(256) void lm_add_ln_fwd_kernel(const float* __restr
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
     const long long e = row * C + lane + 64 * q;
-    const float a = (x ? x[e] : 0.f) + (hh ? hh[e] * lm_keep((unsigned long long)e, key, thr, dscale) : 0.f);
+    const float hb = hbias ? hbias[lane + 64 * q] : 0.f;
+    const float a = (x ? x[e] : 0.f) + (hh ? (hh[e] + hb) * lm_keep((unsigned long long)e, key, thr, dscale) : 0.f);
     v[q] = a; s += a;
   }
   const float mean = wave_sum(s) / (float)C;
@@ -289,20 +319,23 @@ __global__ __launch_bounds__(256) void lm_add_ln_fwd_kernel(const float* __restr
   if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
 }
 // xhat recomputed from (x, h, stats); g = dy gamma; dpre = rstd (g - mean(g) - xhat mean(g xhat)); dx = dpre (if dx),
-// dh = dpre * mask (if dh); dgamma / dbeta partials per workgroup (LN_RPB rows, LN_RPB / 4 per wave) -> part [nwg][2][C]
-constexpr int LN_RPB = 16;
+// dh = dpre * mask (if dh); dgamma / dbeta / dhbias (= column sums of dh) partials per workgroup (LN_RPB rows) -> part [nwg][3][C]
+constexpr int LN_RPB = 4;
 template <int PER>
 __global__ __launch_bounds__(256) void lm_add_ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ hh,
+                                                            const float* __restrict__ hbias,
                                                             const float* __restrict__ dy, const float* __restrict__ gamma,
                                                             const float* __restrict__ stats, float* __restrict__ dx,
                                                             float* __restrict__ dh, float* __restrict__ part, long long rows,
                                                             unsigned key, unsigned thr, float dscale) {
   constexpr int C = PER * 64;
-  extern __shared__ float red[];                              // [4][2][C]
+  extern __shared__ float red[];                              // [4][3][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float pg[PER], pb[PER], gm[PER];
+  float pg[PER], pb[PER], ph[PER], gm[PER], hb[PER];
 #pragma unroll
-  for (int q = 0; q < PER; ++q) { pg[q] = 0.f; pb[q] = 0.f; gm[q] = gamma[lane + 64 * q]; }
+  for (int q = 0; q < PER; ++q) {
+    pg[q] = 0.f; pb[q] = 0.f; ph[q] = 0.f; gm[q] = gamma[lane + 64 * q]; hb[q] = hbias ? hbias[lane + 64 * q] : 0.f;
+  }
   for (int rr = 0; rr < LN_RPB / 4; ++rr) {
     const long long row = (long long)blockIdx.x * LN_RPB + wave * (LN_RPB / 4) + rr;
     if (row >= rows) break;                                   // wave-uniform
@@ -313,7 +346,7 @@ __global__ __launch_bounds__(256) void lm_add_ln_bwd_kernel(const float* __restr
     for (int q = 0; q < PER; ++q) {
       const long long e = row * C + lane + 64 * q;
       const float dyv = dy[e];
-      const float pre = (x ? x[e] : 0.f) + (hh ? hh[e] * lm_keep((unsigned long long)e, key, thr, dscale) : 0.f);
+      const float pre = (x ? x[e] : 0.f) + (hh ? (hh[e] + hb[q]) * lm_keep((unsigned long long)e, key, thr, dscale) : 0.f);
       const float xv = (pre - mean) * rstd, gv = dyv * gm[q];
       xh[q] = xv; g[q] = gv; sg += gv; sgx = fmaf(gv, xv, sgx);
       pg[q] = fmaf(dyv, xv, pg[q]); pb[q] += dyv;
@@ -324,21 +357,24 @@ __global__ __launch_bounds__(256) void lm_add_ln_bwd_kernel(const float* __restr
       const long long e = row * C + lane + 64 * q;
       const float dpre = rstd * (g[q] - sg - xh[q] * sgx);
       if (dx) dx[e] = dpre;
-      if (dh) dh[e] = dpre * lm_keep((unsigned long long)e, key, thr, dscale);
+      const float dhv = dpre * lm_keep((unsigned long long)e, key, thr, dscale);
+      if (dh) dh[e] = dhv;
+      ph[q] += dhv;
     }
   }
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
-    red[(wave * 2 + 0) * C + lane + 64 * q] = pg[q];
-    red[(wave * 2 + 1) * C + lane + 64 * q] = pb[q];
+    red[(wave * 3 + 0) * C + lane + 64 * q] = pg[q];
+    red[(wave * 3 + 1) * C + lane + 64 * q] = pb[q];
+    red[(wave * 3 + 2) * C + lane + 64 * q] = ph[q];
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float a = 0.f, bsum = 0.f;
+  for (int c = threadIdx.x; c < 3 * C; c += 256) {
+    const int plane = c / C, cc = c % C;
+    float a = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { a += red[(w * 2 + 0) * C + c]; bsum += red[(w * 2 + 1) * C + c]; }
-    part[((size_t)blockIdx.x * 2 + 0) * C + c] = a;
-    part[((size_t)blockIdx.x * 2 + 1) * C + c] = bsum;
+    for (int w = 0; w < 4; ++w) a += red[(w * 3 + plane) * C + cc];
+    part[(size_t)blockIdx.x * 3 * C + c] = a;
   }
 }
 #define LM_LN_DISPATCH(dim, CALL)                                                       \
@@ -348,19 +384,23 @@ __global__ __launch_bounds__(256) void lm_add_ln_bwd_kernel(const float* __restr
     case 32: CALL(32); break;                                                           \
     default: SMT_CHECK_ARG(false, "add_ln: dim %d not built (64 x {1,2,4,8,12,16,32})", (int)(dim)); \
   }
-// fixed-order column sums of part [n][planes * C] -> out [planes * C]: a workgroup takes 64 columns, its four waves a
-// quarter of the rows each (in order), and the four partial sums are added in wave order.
+// fixed-order column sums of part [n][width] -> out [width]: a workgroup takes 64 columns, its four waves a quarter of
+// the rows each; a wave keeps eight loads in flight (row r goes to accumulator r % 8) and the partial sums are combined
+// in a fixed order.
 __global__ __launch_bounds__(256) void lm_colsum_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int width) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = blockIdx.x * 64 + lane;
   const int per = (n + 3) / 4, lo = wave * per, hi = min(n, lo + per);
-  float s0 = 0.f, s1 = 0.f;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (c < width) {
     int i = lo;
-    for (; i + 1 < hi; i += 2) { s0 += part[(size_t)i * width + c]; s1 += part[(size_t)(i + 1) * width + c]; }
-    if (i < hi) s0 += part[(size_t)i * width + c];
+    for (; i + 7 < hi; i += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s[u] += part[(size_t)(i + u) * width + c];
+    }
+    for (int u = 0; i < hi; ++i, ++u) s[u] += part[(size_t)i * width + c];
   }
-  red[wave][lane] = s0 + s1;
+  red[wave][lane] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
   __syncthreads();
   if (wave == 0 && c < width) out[c] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
@@ -472,44 +512,39 @@ extern "C" int smt_lm_attention_fwd(const float* qkv, const int* lens, float* ct
   SMT_CHECK_ARG(qkv && ctx && lse, "smt_lm_attention_fwd: null pointer");
   SMT_CHECK_ARG(len <= LM_MAXL && heads >= 1, "smt_lm_attention_fwd: len must be <= %d (got %d)", LM_MAXL, len);
   SMT_CHECK_ARG((long long)batch * heads <= 65535, "smt_lm_attention_fwd: batch * heads must be <= 65535");
-  const size_t lds = 2 * (size_t)len * AT_LD * sizeof(float);
-  (void)hipFuncSetAttribute((const void*)lm_attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  const dim3 grid((len + AT_ROWS - 1) / AT_ROWS, batch * heads);
-  lm_attn_fwd_kernel<<<grid, 256, lds, stream>>>(qkv, lens, ctx, lse, len, heads, causal, drop_key, drop_thresh16, drop_scale);
+  lm_attn_fwd_kernel<<<dim3((len + 31) / 32, batch * heads), 256, 0, stream>>>(qkv, lens, ctx, lse, len, heads, causal, drop_key,
+                                                                           drop_thresh16, drop_scale);
   SMT_CHECK_LAUNCH("lm_attention_fwd");
   return 0;
 }
 
 extern "C" int smt_lm_attention_bwd(const float* qkv, const int* lens, const float* ctx, const float* lse, const float* dctx,
-                                    float* dqkv, int batch, int len, int heads, int causal, uint32_t drop_key,
+                                    float* dqkv, float* delta, int batch, int len, int heads, int causal, uint32_t drop_key,
                                     uint32_t drop_thresh16, float drop_scale, smt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (batch <= 0 || len <= 0) return 0;
-  SMT_CHECK_ARG(qkv && ctx && lse && dctx && dqkv, "smt_lm_attention_bwd: null pointer");
+  SMT_CHECK_ARG(qkv && ctx && lse && dctx && dqkv && delta, "smt_lm_attention_bwd: null pointer");
   SMT_CHECK_ARG(len <= LM_MAXL && heads >= 1, "smt_lm_attention_bwd: len must be <= %d (got %d)", LM_MAXL, len);
   SMT_CHECK_ARG((long long)batch * heads <= 65535, "smt_lm_attention_bwd: batch * heads must be <= 65535");
-  const dim3 grid((len + AT_ROWS - 1) / AT_ROWS, batch * heads);
-  const size_t lds_q = 2 * (size_t)len * AT_LD * sizeof(float);
-  (void)hipFuncSetAttribute((const void*)lm_attn_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
-  lm_attn_dq_kernel<<<grid, 256, lds_q, stream>>>(qkv, lens, ctx, lse, dctx, dqkv, len, heads, causal, drop_key, drop_thresh16,
-                                                 drop_scale);
+  const dim3 grid((len + 31) / 32, batch * heads);
+  lm_attn_dq_kernel<<<grid, 256, 0, stream>>>(qkv, lens, ctx, lse, dctx, dqkv, delta, len, heads, causal, drop_key, drop_thresh16,
+                                            drop_scale);
   SMT_CHECK_LAUNCH("lm_attention_dq");
-  const size_t lds_k = (2 * (size_t)len * AT_LD + 2 * (size_t)len) * sizeof(float);
-  (void)hipFuncSetAttribute((const void*)lm_attn_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
-  lm_attn_dkv_kernel<<<grid, 256, lds_k, stream>>>(qkv, lens, ctx, lse, dctx, dqkv, len, heads, causal, drop_key, drop_thresh16,
-                                                  drop_scale);
+  lm_attn_dkv_kernel<<<grid, 256, 0, stream>>>(qkv, lens, lse, dctx, delta, dqkv, len, heads, causal, drop_key, drop_thresh16,
+                                             drop_scale);
   SMT_CHECK_LAUNCH("lm_attention_dkv");
   return 0;
 }
 
-extern "C" int smt_lm_add_ln_fwd(const float* x, const float* h, const float* gamma, const float* beta, float* y, float* stats,
+extern "C" int smt_lm_add_ln_fwd(const float* x, const float* h, const float* h_bias, const float* gamma, const float* beta, float* y,
+                                 float* stats,
                                  int64_t rows, int dim, float eps, uint32_t drop_key, uint32_t drop_thresh16, float drop_scale,
                                  smt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (rows <= 0) return 0;
   SMT_CHECK_ARG((x || h) && gamma && beta && y && stats, "smt_lm_add_ln_fwd: null pointer");
   SMT_CHECK_ARG(dim % 64 == 0 && dim <= 2048, "smt_lm_add_ln_fwd: dim must be a multiple of 64 up to 2048 (got %d)", dim);
-#define LM_CALL(P) lm_add_ln_fwd_kernel<P><<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>(x, h, gamma, beta, y, stats, rows, eps, \
+#define LM_CALL(P) lm_add_ln_fwd_kernel<P><<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>(x, h, h_bias, gamma, beta, y, stats, rows, eps, \
                                                                                      drop_key, drop_thresh16, drop_scale)
   LM_LN_DISPATCH(dim, LM_CALL)
 #undef LM_CALL
@@ -518,33 +553,33 @@ extern "C" int smt_lm_add_ln_fwd(const float* x, const float* h, const float* ga
 }
 
 extern "C" size_t smt_lm_add_ln_bwd_workspace_bytes(int64_t rows, int dim) {
-  return (size_t)((rows + LN_RPB - 1) / LN_RPB) * 2 * dim * sizeof(float);
+  return (size_t)((rows + LN_RPB - 1) / LN_RPB) * 3 * dim * sizeof(float);
 }
 
-extern "C" int smt_lm_add_ln_bwd(const float* x, const float* h, const float* dy, const float* gamma, const float* stats,
-                                 float* dx, float* dh, float* dgamma, float* dbeta, int64_t rows, int dim, uint32_t drop_key,
+extern "C" int smt_lm_add_ln_bwd(const float* x, const float* h, const float* h_bias, const float* dy, const float* gamma,
+                                 const float* stats, float* dx, float* dh, float* dparams, int64_t rows, int dim, uint32_t drop_key,
                                  uint32_t drop_thresh16, float drop_scale, void* workspace, size_t workspace_bytes,
                                  smt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  SMT_CHECK_ARG(dgamma && dbeta, "smt_lm_add_ln_bwd: null pointer");
+  SMT_CHECK_ARG(dparams, "smt_lm_add_ln_bwd: null pointer");
   if (rows <= 0) {
-    (void)hipMemsetAsync(dgamma, 0, dim * sizeof(float), stream);
-    (void)hipMemsetAsync(dbeta, 0, dim * sizeof(float), stream);
+    (void)hipMemsetAsync(dparams, 0, 3 * (size_t)dim * sizeof(float), stream);
     return 0;
   }
   SMT_CHECK_ARG((x || h) && dy && gamma && stats && workspace, "smt_lm_add_ln_bwd: null pointer");
   SMT_CHECK_ARG(dim % 64 == 0 && dim <= 2048, "smt_lm_add_ln_bwd: dim must be a multiple of 64 up to 2048 (got %d)", dim);
   SMT_CHECK_ARG(workspace_bytes >= smt_lm_add_ln_bwd_workspace_bytes(rows, dim), "smt_lm_add_ln_bwd: workspace too small");
   const int nblk = (int)((rows + LN_RPB - 1) / LN_RPB);
-  float* part = (float*)workspace;
-  // part [nblk][2][dim]: plane 0 = dgamma, plane 1 = dbeta; dgamma and dbeta must be adjacent for the one reduction
-  SMT_CHECK_ARG(dbeta == dgamma + dim, "smt_lm_add_ln_bwd: dbeta must follow dgamma (one [2][dim] buffer)");
-#define LM_CALL(P) lm_add_ln_bwd_kernel<P><<<nblk, 256, 8 * dim * sizeof(float), stream>>>(x, h, dy, gamma, stats, dx, dh, part, rows, \
-                                                                                      drop_key, drop_thresh16, drop_scale)
+  float* part = (float*)workspace;                           // [nblk][3][dim]: dgamma, dbeta, dh_bias partials
+  const size_t lds = 12 * (size_t)dim * sizeof(float);
+#define LM_CALL(P)                                                                                                        \
+  (void)hipFuncSetAttribute((const void*)lm_add_ln_bwd_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+  lm_add_ln_bwd_kernel<P><<<nblk, 256, lds, stream>>>(x, h, h_bias, dy, gamma, stats, dx, dh, part, rows, drop_key,        \
+                                                      drop_thresh16, drop_scale)
   LM_LN_DISPATCH(dim, LM_CALL)
 #undef LM_CALL
   SMT_CHECK_LAUNCH("lm_add_ln_bwd");
-  lm_colsum_kernel<<<(2 * dim + 63) / 64, 256, 0, stream>>>(part, dgamma, nblk, 2 * dim);
+  lm_colsum_kernel<<<(3 * dim + 63) / 64, 256, 0, stream>>>(part, dparams, nblk, 3 * dim);
   SMT_CHECK_LAUNCH("lm_colsum");
   return 0;
 }

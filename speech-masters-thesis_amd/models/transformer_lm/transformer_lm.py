@@ -67,11 +67,13 @@ class _EncoderLayer(nn.Module):
         sa, tr, p = self.self_attn, self.training, self.p
         qkv = F.linear(x, sa.in_proj_weight, sa.in_proj_bias)
         ctx = K.attention(qkv, lens, sa.num_heads, causal, K.Drop(p, tr, seed, site0))
-        a = F.linear(ctx, sa.out_proj.weight, sa.out_proj.bias)
-        x = K.add_layer_norm(x, a, self.norm1.weight, self.norm1.bias, self.norm1.eps, K.Drop(p, tr, seed, site0 + 1))
+        a = F.linear(ctx, sa.out_proj.weight)                      # its bias is added (and differentiated) inside add_layer_norm
+        x = K.add_layer_norm(x, a, self.norm1.weight, self.norm1.bias, self.norm1.eps, K.Drop(p, tr, seed, site0 + 1),
+                             h_bias=sa.out_proj.bias)
         f = K.bias_relu_dropout_(F.linear(x, self.linear1.weight), self.linear1.bias, K.Drop(p, tr, seed, site0 + 2))
-        f = F.linear(f, self.linear2.weight, self.linear2.bias)
-        return K.add_layer_norm(x, f, self.norm2.weight, self.norm2.bias, self.norm2.eps, K.Drop(p, tr, seed, site0 + 3))
+        f = F.linear(f, self.linear2.weight)
+        return K.add_layer_norm(x, f, self.norm2.weight, self.norm2.bias, self.norm2.eps, K.Drop(p, tr, seed, site0 + 3),
+                                h_bias=self.linear2.bias)
 
 
 class _Encoder(nn.Module):

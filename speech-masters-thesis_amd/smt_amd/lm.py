@@ -84,7 +84,9 @@ class _Attention(torch.autograd.Function):
         heads, causal, drop = ctx.meta
         b, l, _ = qkv.shape
         dqkv = torch.empty_like(qkv)
-        N.check(N.lib().smt_lm_attention_bwd(N.ptr(qkv), N.ptr(lens), N.ptr(out), N.ptr(lse), N.ptr(_f32(dout)), N.ptr(dqkv), b, l,
+        delta = torch.empty_like(lse)
+        N.check(N.lib().smt_lm_attention_bwd(N.ptr(qkv), N.ptr(lens), N.ptr(out), N.ptr(lse), N.ptr(_f32(dout)), N.ptr(dqkv),
+                                             N.ptr(delta), b, l,
                                              heads, causal, drop.key, drop.thresh, drop.scale, N.stream_ptr()),
                 "smt_lm_attention_bwd")
         return dqkv, None, None, None, None
@@ -100,7 +102,7 @@ def attention(qkv, lens, heads, causal=True, drop=NO_DROP):
 
 class _AddLayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, h, gamma, beta, eps, drop):
+    def forward(ctx, x, h, h_bias, gamma, beta, eps, drop):
         src = x if x is not None else h
         d = src.shape[-1]
         rows = src.numel() // d
@@ -108,32 +110,35 @@ class _AddLayerNorm(torch.autograd.Function):
         h = _f32(h) if h is not None else None
         y = torch.empty_like(src, memory_format=torch.contiguous_format)
         stats = torch.empty(rows, 2, device=src.device, dtype=torch.float32)
-        N.check(N.lib().smt_lm_add_ln_fwd(N.ptr(x), N.ptr(h), N.ptr(_f32(gamma)), N.ptr(_f32(beta)), N.ptr(y), N.ptr(stats), rows,
-                                          d, eps, drop.key, drop.thresh, drop.scale, N.stream_ptr()), "smt_lm_add_ln_fwd")
-        ctx.save_for_backward(x, h, gamma, stats)
+        N.check(N.lib().smt_lm_add_ln_fwd(N.ptr(x), N.ptr(h), N.ptr(h_bias), N.ptr(_f32(gamma)), N.ptr(_f32(beta)), N.ptr(y),
+                                          N.ptr(stats), rows, d, eps, drop.key, drop.thresh, drop.scale, N.stream_ptr()),
+                "smt_lm_add_ln_fwd")
+        ctx.save_for_backward(x, h, h_bias, gamma, stats)
         ctx.meta = (rows, d, drop)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, h, gamma, stats = ctx.saved_tensors
+        x, h, h_bias, gamma, stats = ctx.saved_tensors
         rows, d, drop = ctx.meta
         lib = N.lib()
         dy = _f32(dy)
         dx = torch.empty_like(dy) if x is not None and ctx.needs_input_grad[0] else None
         dh = torch.empty_like(dy) if h is not None and ctx.needs_input_grad[1] else None
-        dgb = torch.empty(2, d, device=dy.device, dtype=torch.float32)
+        dparams = torch.empty(3, d, device=dy.device, dtype=torch.float32)
         ws_bytes = lib.smt_lm_add_ln_bwd_workspace_bytes(rows, d)
         ws = torch.empty(ws_bytes, device=dy.device, dtype=torch.uint8)
-        N.check(lib.smt_lm_add_ln_bwd(N.ptr(x), N.ptr(h), N.ptr(dy), N.ptr(_f32(gamma)), N.ptr(stats), N.ptr(dx), N.ptr(dh),
-                                      N.ptr(dgb[0]), N.ptr(dgb[1]), rows, d, drop.key, drop.thresh, drop.scale, N.ptr(ws), ws_bytes,
+        N.check(lib.smt_lm_add_ln_bwd(N.ptr(x), N.ptr(h), N.ptr(h_bias), N.ptr(dy), N.ptr(_f32(gamma)), N.ptr(stats), N.ptr(dx),
+                                      N.ptr(dh), N.ptr(dparams), rows, d, drop.key, drop.thresh, drop.scale, N.ptr(ws), ws_bytes,
                                       N.stream_ptr()), "smt_lm_add_ln_bwd")
-        return dx, dh, dgb[0], dgb[1], None, None
+        return dx, dh, (dparams[2] if h_bias is not None else None), dparams[0], dparams[1], None, None
 
 
-def add_layer_norm(x, h, gamma, beta, eps=1e-5, drop=NO_DROP):
-    """LayerNorm(x + dropout(h)) (post-norm sub-layer of nn.TransformerEncoderLayer); h = None -> LayerNorm(x)."""
-    return _AddLayerNorm.apply(x, h, gamma, beta, eps, drop)
+def add_layer_norm(x, h, gamma, beta, eps=1e-5, drop=NO_DROP, h_bias=None):
+    """LayerNorm(x + dropout(h + h_bias)) (post-norm sub-layer of nn.TransformerEncoderLayer; h_bias = the bias of the
+    projection that produced h, whose gradient then comes out of this op's backward); h = None -> LayerNorm(x)."""
+    assert h_bias is None or (h is not None and h_bias.dtype == torch.float32 and h_bias.is_contiguous())
+    return _AddLayerNorm.apply(x, h, h_bias, gamma, beta, eps, drop)
 
 
 class _BiasReluDrop(torch.autograd.Function):

@@ -76,9 +76,9 @@ _SIGNATURES = {
     "smt_lm_embed_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_f32, c_u32, c_u32, c_f32, c_i64,
                                  c_ptr]),
     "smt_lm_attention_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_u32, c_u32, c_f32, c_ptr]),
-    "smt_lm_attention_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_u32, c_u32, c_f32,
+    "smt_lm_attention_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_u32, c_u32, c_f32,
                                      c_ptr]),
-    "smt_lm_add_ln_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_u32, c_u32, c_f32,
+    "smt_lm_add_ln_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_u32, c_u32, c_f32,
                                   c_ptr]),
     "smt_lm_add_ln_bwd_workspace_bytes": (c_size, [c_i64, c_int]),
     "smt_lm_add_ln_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_u32,

@@ -64,23 +64,25 @@ def test_attention_kernel_forward_and_backward(causal, ragged, p, b, l, h):
     assert torch.allclose(qg.grad.cpu(), q64.grad.float(), atol=5e-5)
 
 
-@pytest.mark.parametrize("rows,dim,p,with_x,with_h", [(37, 64, 0.1, True, True), (130, 512, 0.1, True, True), (9, 512, 0.0, True, False),
-                                                       (5, 2048, 0.0, False, True), (8, 768, 0.2, True, True)])
-def test_add_layer_norm_kernel(rows, dim, p, with_x, with_h):
+@pytest.mark.parametrize("rows,dim,p,with_x,with_h,with_bias", [(37, 64, 0.1, True, True, True), (130, 512, 0.1, True, True, True),
+                                                                 (9, 512, 0.0, True, False, False), (5, 2048, 0.0, False, True, True),
+                                                                 (8, 768, 0.2, True, True, False)])
+def test_add_layer_norm_kernel(rows, dim, p, with_x, with_h, with_bias):
     from smt_amd import lm as K
     g = torch.Generator().manual_seed(rows)
     x = torch.randn(rows, dim, generator=g) if with_x else None
     h = torch.randn(rows, dim, generator=g) * 2 if with_h else None
+    hb = torch.randn(dim, generator=g) if with_bias else None
     gamma, beta = 1 + 0.2 * torch.randn(dim, generator=g), 0.2 * torch.randn(dim, generator=g)
     gamma[3] = 0.0                                                  # a dead scale: its xhat must still reach dgamma
     dy = torch.randn(rows, dim, generator=g)
     drop = lmo.CounterDropout(seed=9, p=p)
-    leaves = [t.double().requires_grad_(True) if t is not None else None for t in (x, h, gamma, beta)]
-    pre = (leaves[0] if with_x else 0) + (drop(2, leaves[1]) if with_h else 0)
+    leaves = [t.double().requires_grad_(True) if t is not None else None for t in (x, h, gamma, beta, hb)]
+    pre = (leaves[0] if with_x else 0) + (drop(2, leaves[1] + (leaves[4] if with_bias else 0)) if with_h else 0)
     ref = F.layer_norm(pre, (dim,), leaves[2], leaves[3], 1e-5)
     ref.backward(dy.double())
-    dev = [t.to(DEV).requires_grad_(True) if t is not None else None for t in (x, h, gamma, beta)]
-    out = K.add_layer_norm(dev[0], dev[1], dev[2], dev[3], 1e-5, K.Drop(p, True, 9, 2))
+    dev = [t.to(DEV).requires_grad_(True) if t is not None else None for t in (x, h, gamma, beta, hb)]
+    out = K.add_layer_norm(dev[0], dev[1], dev[2], dev[3], 1e-5, K.Drop(p, True, 9, 2), h_bias=dev[4])
     out.backward(dy.to(DEV))
     assert torch.allclose(out.cpu(), ref.float(), atol=2e-5)
     for mine, want in zip(dev, leaves):

@@ -33,6 +33,11 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0
 
 def parse(argv=None):
     p = argparse.ArgumentParser()
+    p.add_argument("--workload", choices=["vqvae", "transformer_lm"], default="vqvae",
+                   help="vqvae = the headline metric (BASELINE.json); transformer_lm = the SURVEY 8(f2) train step, reported "
+                        "in the same format under its own metric name")
+    p.add_argument("--lm_batch", type=int, default=8, help="sequences per GPU (scripts/train_transformer_lm.sh: 8)")
+    p.add_argument("--lm_len", type=int, default=258, help="tokens per sequence (<bos> + 256 codes + pad)")
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=3)
@@ -118,6 +123,112 @@ def cpu_baseline(args):
                       f"{med:.2f} s/step (min {min(times):.2f}, max {max(times):.2f}); value = {frac:.3f} / median"}
 
 
+def lm_cpu_baseline(args):
+    """The TransformerLM oracle (oracle/lm_oracle.py: the reference's forward restated op by op, torch-CPU fp32, autograd
+    backward) on this box's host cores: one warm-up + 3 timed forward + backward passes of the SAME batch shape, median."""
+    import statistics
+    from oracle import lm_oracle as lmo
+    cores = usable_cpus()
+    torch.set_num_threads(cores)
+    p = {k: v.requires_grad_(True) for k, v in lmo.init_params(512, 512, 16, 2048, 12, seed=0).items()}
+    x, lens = lmo.synthetic_tokens(args.lm_batch, args.lm_len, 512, seed=1, ragged=False)
+    times = []
+    for i in range(4):
+        t0 = time.perf_counter()
+        logits = lmo.lm_logits(x, lens, p, heads=16, num_layers=12, drop=lmo.CounterDropout(seed=i, p=0.1))
+        loss, _ = lmo.lm_loss(x, logits)
+        loss.backward()
+        for v in p.values():
+            v.grad = None
+        if i:
+            times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return {"value": args.lm_batch * args.lm_len / med, "unit": "tokens/s", "cores": cores, "threads": torch.get_num_threads(),
+            "kind": "port", "sample": f"oracle forward + backward (no optimizer), fp32 torch-CPU, {args.lm_batch} x {args.lm_len} "
+                                      f"tokens, 1 warm-up + 3 timed, median {med:.2f} s"}
+
+
+def lm_main(args, rank, world, device, rehearsal):
+    """`--workload transformer_lm`: tokens/s of the TransformerLM train step on the reference's
+    configuration (configs/models/transformer_lm.yaml) and batch shape, same protocol as the headline run."""
+    import tempfile
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import bench_lm
+    from smt_amd import native, profiler
+    from smt_amd.dist import GradSync
+    native.lib()
+    with tempfile.TemporaryDirectory() as tmp:
+        model, optimizer, scheduler = bench_lm.build(tmp, "fp32", device)
+    grad_sync = GradSync([p for p in model.parameters() if p.requires_grad], timing=True) if world > 1 else None
+    g = torch.Generator().manual_seed(1 + rank)
+    pool = []
+    for _ in range(4):
+        x = torch.randint(2, 514, (args.lm_batch, args.lm_len), generator=g)
+        x[:, 0], x[:, -1] = 1, 0
+        pool.append((x.to(device), torch.full((args.lm_batch,), args.lm_len - 1).to(device)))
+    model.train()
+
+    def step(i):
+        x, lens = pool[i % len(pool)]
+        if grad_sync is not None:
+            grad_sync.zero_grad()                 # gradients live in the flat all-reduce buffer
+        else:
+            optimizer.zero_grad(set_to_none=True)
+        out, _ = model(x, lens, None, None)
+        out["loss"].backward()
+        if grad_sync is not None:
+            grad_sync.finish()
+        optimizer.step()
+        scheduler.step()
+        return out["loss"]
+
+    for i in range(args.warmup):
+        step(i)
+    profiler.reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_prof = 0
+    for i in range(args.steps):
+        prof = (not args.no_kernel_events) and i % max(1, args.event_every) == 0
+        profiler.enable(prof)
+        n_prof += int(prof)
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    profiler.enable(False)
+    if world > 1:
+        mine = torch.tensor([elapsed], device=device)
+        every_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every_rank, mine)
+        elapsed = max(t.item() for t in every_rank)
+    if rank == 0:
+        kernels = profiler.summary()
+        dom = next((k for k in kernels if k["name"] == "lm_attention:bwd"), None)
+        roofline = None if dom is None else {
+            "kernel": "lm_attention:bwd (lm_attn_dq_kernel + lm_attn_dkv_kernel)", "bound": "mfma", "achieved": dom["achieved"],
+            "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"], "traffic": None, "avg_us": dom["avg_us"],
+            "note": "largest hand-written kernel of the step (the dense projections are hipBLASLt f32 GEMMs); algorithmic FLOPs = "
+                    "5 products x 64 per visible (query, key) pair against the f32-input MFMA peak"}
+        line = {"metric": "TransformerLM train tokens/sec (SURVEY 8(f2); not the BASELINE.json headline)",
+                "value": args.lm_batch * args.lm_len * world * args.steps / elapsed, "unit": "tokens/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "rehearsal_shared_gpu": bool(rehearsal),
+                "config": {"workload": "models/transformer_lm (12 x d512, 16 heads, ff 2048, dropout 0.1, CE), "
+                                       f"batch {args.lm_batch}/GPU x {args.lm_len} tokens, fp32, AdamW",
+                           "global_batch": args.lm_batch * world, "seq_len": args.lm_len, "parallelism": f"dp{world}"},
+                "loss": float(loss.detach()), "roofline": roofline, "kernels": kernels, "kernel_event_steps": n_prof}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = lm_cpu_baseline(args)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def launch_or_none(args, argv):
     """`python bench.py --gpus N` with N > 1 outside torchrun: start N rank processes of this script (fresh
     interpreters; this parent makes no HIP call) and return their exit code.  None = run in this process."""
@@ -181,6 +292,9 @@ def main(argv=None):
     device = torch.device("cuda", local)
     if world > 1:
         dist.init_process_group(backend="gloo" if rehearsal else "nccl", init_method="env://")
+
+    if args.workload == "transformer_lm":
+        return lm_main(args, rank, world, device, rehearsal)
 
     from smt_amd import native, profiler
     native.lib()  # fail loudly if the HIP library is missing

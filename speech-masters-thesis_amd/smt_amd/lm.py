@@ -11,6 +11,7 @@ import math
 import torch
 
 from . import native as N
+from . import profiler
 from .convops import dropout_key
 
 
@@ -63,6 +64,14 @@ def embed(tokens, weight, pe, drop=NO_DROP, padding_idx=0):
     return _Embed.apply(tokens, weight, pe, math.sqrt(weight.shape[1]), drop, padding_idx)
 
 
+def _attn_flops(b, heads, l, causal, matmuls):
+    """Algorithmic FLOPs of `matmuls` 32-channel products over the visible (query, key) pairs (full lengths): forward 2
+    (scores, context), backward 5 (scores, dP, dq, dk, dv; the two backward kernels each recompute scores and dP, which
+    is not counted)."""
+    pairs = l * (l + 1) // 2 if causal else l * l
+    return b * heads * pairs * 64 * matmuls
+
+
 class _Attention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, lens, heads, causal, drop):
@@ -72,8 +81,9 @@ class _Attention(torch.autograd.Function):
         qkv = _f32(qkv)
         out = torch.empty(b, l, d, device=qkv.device, dtype=torch.float32)
         lse = torch.empty(b, heads, l, device=qkv.device, dtype=torch.float32)
-        N.check(N.lib().smt_lm_attention_fwd(N.ptr(qkv), N.ptr(lens), N.ptr(out), N.ptr(lse), b, l, heads, int(causal), drop.key,
-                                             drop.thresh, drop.scale, N.stream_ptr()), "smt_lm_attention_fwd")
+        with profiler.region("lm_attention:fwd", flops=_attn_flops(b, heads, l, causal, 2), bound="mfma", dtype="f32"):
+            N.check(N.lib().smt_lm_attention_fwd(N.ptr(qkv), N.ptr(lens), N.ptr(out), N.ptr(lse), b, l, heads, int(causal),
+                                                 drop.key, drop.thresh, drop.scale, N.stream_ptr()), "smt_lm_attention_fwd")
         ctx.save_for_backward(qkv, lens, out, lse)
         ctx.meta = (heads, int(causal), drop)
         return out
@@ -85,10 +95,11 @@ class _Attention(torch.autograd.Function):
         b, l, _ = qkv.shape
         dqkv = torch.empty_like(qkv)
         delta = torch.empty_like(lse)
-        N.check(N.lib().smt_lm_attention_bwd(N.ptr(qkv), N.ptr(lens), N.ptr(out), N.ptr(lse), N.ptr(_f32(dout)), N.ptr(dqkv),
-                                             N.ptr(delta), b, l,
-                                             heads, causal, drop.key, drop.thresh, drop.scale, N.stream_ptr()),
-                "smt_lm_attention_bwd")
+        dout = _f32(dout)
+        with profiler.region("lm_attention:bwd", flops=_attn_flops(b, heads, l, causal, 5), bound="mfma", dtype="f32"):
+            N.check(N.lib().smt_lm_attention_bwd(N.ptr(qkv), N.ptr(lens), N.ptr(out), N.ptr(lse), N.ptr(dout), N.ptr(dqkv),
+                                                 N.ptr(delta), b, l, heads, causal, drop.key, drop.thresh, drop.scale,
+                                                 N.stream_ptr()), "smt_lm_attention_bwd")
         return dqkv, None, None, None, None
 
 
@@ -110,9 +121,11 @@ class _AddLayerNorm(torch.autograd.Function):
         h = _f32(h) if h is not None else None
         y = torch.empty_like(src, memory_format=torch.contiguous_format)
         stats = torch.empty(rows, 2, device=src.device, dtype=torch.float32)
-        N.check(N.lib().smt_lm_add_ln_fwd(N.ptr(x), N.ptr(h), N.ptr(h_bias), N.ptr(_f32(gamma)), N.ptr(_f32(beta)), N.ptr(y),
-                                          N.ptr(stats), rows, d, eps, drop.key, drop.thresh, drop.scale, N.stream_ptr()),
-                "smt_lm_add_ln_fwd")
+        n_in = (x is not None) + (h is not None)
+        with profiler.region("lm_add_ln:fwd", nbytes=(n_in + 1) * rows * d * 4, bound="hbm"):
+            N.check(N.lib().smt_lm_add_ln_fwd(N.ptr(x), N.ptr(h), N.ptr(h_bias), N.ptr(_f32(gamma)), N.ptr(_f32(beta)), N.ptr(y),
+                                              N.ptr(stats), rows, d, eps, drop.key, drop.thresh, drop.scale, N.stream_ptr()),
+                    "smt_lm_add_ln_fwd")
         ctx.save_for_backward(x, h, h_bias, gamma, stats)
         ctx.meta = (rows, d, drop)
         return y
@@ -128,9 +141,11 @@ class _AddLayerNorm(torch.autograd.Function):
         dparams = torch.empty(3, d, device=dy.device, dtype=torch.float32)
         ws_bytes = lib.smt_lm_add_ln_bwd_workspace_bytes(rows, d)
         ws = torch.empty(ws_bytes, device=dy.device, dtype=torch.uint8)
-        N.check(lib.smt_lm_add_ln_bwd(N.ptr(x), N.ptr(h), N.ptr(h_bias), N.ptr(dy), N.ptr(_f32(gamma)), N.ptr(stats), N.ptr(dx),
-                                      N.ptr(dh), N.ptr(dparams), rows, d, drop.key, drop.thresh, drop.scale, N.ptr(ws), ws_bytes,
-                                      N.stream_ptr()), "smt_lm_add_ln_bwd")
+        n_io = 1 + (x is not None) + (h is not None) + (dx is not None) + (dh is not None)
+        with profiler.region("lm_add_ln:bwd", nbytes=n_io * rows * d * 4, bound="hbm"):
+            N.check(lib.smt_lm_add_ln_bwd(N.ptr(x), N.ptr(h), N.ptr(h_bias), N.ptr(dy), N.ptr(_f32(gamma)), N.ptr(stats), N.ptr(dx),
+                                          N.ptr(dh), N.ptr(dparams), rows, d, drop.key, drop.thresh, drop.scale, N.ptr(ws),
+                                          ws_bytes, N.stream_ptr()), "smt_lm_add_ln_bwd")
         return dx, dh, (dparams[2] if h_bias is not None else None), dparams[0], dparams[1], None, None
 
 
@@ -147,8 +162,9 @@ class _BiasReluDrop(torch.autograd.Function):
         d = h.shape[-1]
         rows = h.numel() // d
         h = _f32(h)
-        N.check(N.lib().smt_lm_bias_relu_fwd(N.ptr(h), N.ptr(_f32(bias)), rows, d, drop.key, drop.thresh, drop.scale,
-                                             N.stream_ptr()), "smt_lm_bias_relu_fwd")
+        with profiler.region("lm_bias_relu:fwd", nbytes=2 * rows * d * 4, bound="hbm"):
+            N.check(N.lib().smt_lm_bias_relu_fwd(N.ptr(h), N.ptr(_f32(bias)), rows, d, drop.key, drop.thresh, drop.scale,
+                                                 N.stream_ptr()), "smt_lm_bias_relu_fwd")
         ctx.mark_dirty(h)
         ctx.save_for_backward(h)
         ctx.meta = (rows, d, drop)
@@ -164,8 +180,9 @@ class _BiasReluDrop(torch.autograd.Function):
         dbias = torch.empty(d, device=a.device, dtype=torch.float32)
         ws_bytes = lib.smt_lm_bias_relu_bwd_workspace_bytes(rows, d)
         ws = torch.empty(ws_bytes, device=a.device, dtype=torch.uint8)
-        N.check(lib.smt_lm_bias_relu_bwd(N.ptr(a), N.ptr(da), N.ptr(dh), N.ptr(dbias), rows, d, drop.key, drop.thresh, drop.scale, N.ptr(ws),
-                                         ws_bytes, N.stream_ptr()), "smt_lm_bias_relu_bwd")
+        with profiler.region("lm_bias_relu:bwd", nbytes=3 * rows * d * 4, bound="hbm"):
+            N.check(lib.smt_lm_bias_relu_bwd(N.ptr(a), N.ptr(da), N.ptr(dh), N.ptr(dbias), rows, d, drop.key, drop.thresh, drop.scale,
+                                             N.ptr(ws), ws_bytes, N.stream_ptr()), "smt_lm_bias_relu_bwd")
         return dh, dbias, None
 
 

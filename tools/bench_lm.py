@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "speech-masters-thesis_amd"))
 import torch  # noqa: E402
 
 
-def build(tmp, gemm):
+def build(tmp, gemm, device="cuda:0"):
     from models.transformer_lm.transformer_lm import TransformerLM
     from utils import config as C
     from utils.commons import get_model, get_optimizer, setup_logdir
@@ -30,7 +30,7 @@ def build(tmp, gemm):
                   C.create({"train": {"batch_size": 2, "n_gpus": 1, "ema": False, "log_dir": log_dir, "num_workers": 0, "total_epochs": 1}}))
     cfg.model.update(C.create(dict(width=16, emb_width=32, l_bins=512, multipliers=[1, 1, 1])))
     setup_logdir(cfg)
-    vq, ema = get_model(cfg, "cuda:0")
+    vq, ema = get_model(cfg, device)
     opt, sched = get_optimizer(cfg, vq)
     save_checkpoint(cfg, 1, 0, vq, ema, opt, sched)
     lm_cfg = C.load(os.path.join(pkg, "configs/models/transformer_lm.yaml"))
@@ -38,7 +38,7 @@ def build(tmp, gemm):
     if gemm != "fp32":
         lm_cfg.model.gemm_dtype = gemm
     torch.manual_seed(0)
-    model = TransformerLM(lm_cfg).to("cuda:0")
+    model = TransformerLM(lm_cfg).to(device)
     optimizer, scheduler = get_optimizer(lm_cfg, model)
     return model, optimizer, scheduler
 

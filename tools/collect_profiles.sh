@@ -22,4 +22,8 @@ echo "[5/5] PMC MFMA busy + clock"; date
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/mfma -o m -- python $R/bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_kernel_events --no_fp32 > $O/mfma.json 2> $O/mfma.err
 python $R/tools/pmc_mfma.py $O/mfma/m_counter_collection.csv $O/mfma/m_kernel_trace.csv $O/pmc_mfma
 rm -f $O/mfma/*kernel_trace.csv $O/mfma/m_counter_collection.csv
-ls $O $O/stats
+echo "[6/6] TransformerLM workload: bench line + kernel stats"; date
+python $R/bench.py --workload transformer_lm --steps 20 --warmup 5 > $O/lm_bench.json 2> $O/lm_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/lm_stats -o lm -- python $R/bench.py --workload transformer_lm --steps 10 --warmup 3 --no_cpu_baseline --no_kernel_events > $O/lm_stats_bench.json 2> $O/lm_stats_bench.err
+rm -f $O/lm_stats/*kernel_trace.csv
+ls $O $O/stats $O/lm_stats

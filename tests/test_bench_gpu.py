@@ -41,3 +41,17 @@ def test_two_ranks_started_by_bench_itself():
     assert abs(d["ms_per_step"] - max(d["ms_per_step_per_rank"])) < 1e-6          # MAX over ranks
     assert abs(d["value"] - 4 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]    # whole-job utterances/s
     assert d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
+
+
+def test_transformer_lm_workload_line_and_two_rank_rehearsal():
+    """`--workload transformer_lm`: same line format under its own metric; data-parallel ranks keep the
+    gradients in the flat all-reduce buffer (two ranks on the one card over gloo)."""
+    small = ["--workload", "transformer_lm", "--lm_batch", "2", "--lm_len", "66", "--steps", "2", "--warmup", "1", "--no_cpu_baseline"]
+    d = _run(small)
+    assert d["unit"] == "tokens/s" and d["n_gpus"] == 1 and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert abs(d["value"] - 2 * 66 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
+    assert {"lm_attention:fwd", "lm_attention:bwd", "lm_add_ln:fwd", "lm_add_ln:bwd"} <= {k["name"] for k in d["kernels"]}
+    d2 = _run(["--gpus", "2"] + small, env={"SMT_BENCH_REHEARSAL": "1"})
+    assert d2["n_gpus"] == 2 and d2["rehearsal_shared_gpu"] and d2["config"]["global_batch"] == 4
+    assert abs(d2["value"] - 4 * 66 * 1000.0 / d2["ms_per_step"]) < 1e-6 * d2["value"]

@@ -412,7 +412,7 @@ def main(argv=None):
             "conv_k3gate": group({"conv_k3gate"}, "smt::conv_k3gate_kernel (K3 of the four branches + gate, HBM-bound)", "hbm",
                                  dt, "conv_k3gate_kernel"),
             "resample": group({"conv4s2", "convt4s2"}, "smt::conv4s2_kernel / convt4s2_kernel (k4 s2 resampling convs, HBM-bound)",
-                              "hbm", dt),
+                              "hbm", dt, "resample"),
             "conv_k1act": group({"conv_k1act"}, "smt::conv_k1act_kernel (K1, activated output only, HBM-bound)", "hbm",
                                 dt, "conv_k1act_kernel"),
             "conv_k1_bwd": group({"conv_k1_bwd"}, "smt::conv_k1_bwd_kernel (fused K1 backward, HBM-bound)", "hbm", dt,

@@ -337,6 +337,16 @@ def test_train_py_end_to_end_on_generated_codes(tmp_path, monkeypatch):
         with wave.open(os.path.join(log_dir, "audio", "val_audio_2_pred.wav")) as w:
             assert w.getframerate() == 22050 and w.getnframes() >= 24 * 128
         train.main(argv + ["--load_ckpt", os.path.join(log_dir, "ckpts", "ckpt.last.pt")])
+        # scripts/sample_from_lm.py on the run just written: wavs, the spectrogram image, the token table
+        from scripts import sample_from_lm as S
+        out = S.main(["--log_dir", log_dir, "--ckpt_num", "2", "--dump_dir", str(tmp_path / "outputs"), "--n_samples", "2",
+                      "--n_steps", "8"])
+        assert out.endswith("TransformerLM@2")
+        with wave.open(os.path.join(out, "sample_1.wav")) as w:
+            assert w.getnframes() == 8 * 128
+        assert open(os.path.join(out, "mel_spectrograms.png"), "rb").read(8) == b"\x89PNG\r\n\x1a\n"
+        table = open(os.path.join(out, "tokens.txt")).read().splitlines()
+        assert len(table) == 4 and len(table[2].split()) == 8 and all(0 <= int(v) < 16 for v in table[2].split())
     finally:
         os.remove("configs/models/_test_lm.yaml")
         os.remove("configs/datasets/_test_vql.yaml")

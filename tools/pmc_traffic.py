@@ -24,6 +24,9 @@ GROUPS = [  # (key, substrings of the kernel name)
     ("gate_mix", ["gate_mix_fwd_kernel", "gate_mix_bwd_kernel"]),
     ("vq_forward", ["vq_search", "vq_candidates", "vq_exact", "vq_reduce"]),
     ("recon_loss", ["recon_loss_fwd", "recon_loss_bwd"]),
+    ("resample", ["conv4s2_kernel", "convt4s2_kernel"]),
+    ("gate_mix_bwd", ["gate_mix_bwd_kernel"]),
+    ("conv_gate_bwd", ["conv_gate_bwd_kernel"]),
 ]
 
 

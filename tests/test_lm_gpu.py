@@ -350,3 +350,55 @@ def test_train_py_end_to_end_on_generated_codes(tmp_path, monkeypatch):
     finally:
         os.remove("configs/models/_test_lm.yaml")
         os.remove("configs/datasets/_test_vql.yaml")
+
+
+# ------------------------------------------------------------------------------------------------ edge cases
+@pytest.mark.parametrize("b,l,h,lens", [(1, 1, 1, None), (2, 1, 2, [1, 0]), (3, 33, 2, [33, 0, 1]), (2, 64, 1, [64, 32]),
+                                        (1, 512, 1, [300]), (2, 97, 3, [5, 97])])
+def test_attention_edge_shapes(b, l, h, lens):
+    """One token, empty sequences (lens = 0: no visible key -> zero context, zero gradient), block-aligned and maximum
+    lengths, a head count that is not a power of two."""
+    from smt_amd import lm as K
+    g = torch.Generator().manual_seed(100 + l)
+    qkv = torch.randn(b, l, 3 * h * 32, generator=g)
+    dy = torch.randn(b, l, h * 32, generator=g)
+    lens_t = None if lens is None else torch.tensor(lens)
+    q64 = qkv.double().requires_grad_(True)
+    if lens_t is not None and (lens_t == 0).any():
+        # the oracle's softmax over an all-masked row is nan (as torch's own): compare the non-empty items, demand zeros
+        keep = lens_t > 0
+        ref = lmo.attention_core(q64[keep], lens_t[keep], h, True, lmo.CounterDropout(), 0)
+        ref.backward(dy[keep].double())
+    else:
+        keep = torch.ones(b, dtype=torch.bool)
+        ref = lmo.attention_core(q64, lens_t, h, True, lmo.CounterDropout(), 0)
+        ref.backward(dy.double())
+    qg = qkv.to(DEV).requires_grad_(True)
+    out = K.attention(qg, None if lens_t is None else lens_t.to(DEV, torch.int32), h, True)
+    out.backward(dy.to(DEV))
+    assert torch.allclose(out.cpu()[keep], ref.float(), atol=3e-5)
+    assert torch.allclose(qg.grad.cpu()[keep], q64.grad.float()[keep], atol=1e-4)
+    assert float(out.detach().cpu()[~keep].abs().sum()) == 0.0 and float(qg.grad.cpu()[~keep].abs().sum()) == 0.0
+
+
+def test_kernels_accept_empty_batches_and_reject_bad_shapes():
+    from smt_amd import lm as K
+    from smt_amd import native as N
+    e = torch.empty(0, 7, 3 * 64, device=DEV)
+    assert K.attention(e, None, 2).shape == (0, 7, 64)
+    assert K.add_layer_norm(torch.empty(0, 64, device=DEV), None, torch.ones(64, device=DEV), torch.zeros(64, device=DEV)).shape == (0, 64)
+    with pytest.raises(AssertionError, match="head dim 32"):
+        K.attention(torch.randn(1, 4, 3 * 48, device=DEV), None, 1)
+    with pytest.raises(RuntimeError, match="len must be <= 512"):
+        K.attention(torch.randn(1, 513, 3 * 32, device=DEV), None, 1)
+    assert N.lib().smt_lm_add_ln_bwd_workspace_bytes(0, 512) == 0
+
+
+def test_forward_with_no_scored_position_is_nan_like_the_reference(tmp_path):
+    """All targets are pads / specials: the reference's mean over an empty selection is nan (transformer_lm.py:126-128)."""
+    model, _ = _build(tmp_path, **SMALL)
+    x = torch.zeros(2, 9, dtype=torch.long)
+    x[:, 0] = lmo.BOS
+    model.train()
+    out, metrics = model(x.to(DEV), torch.tensor([1, 1]).to(DEV), None, None)
+    assert math.isnan(float(out["loss"])) and math.isnan(float(metrics["accuracy"]))

@@ -33,9 +33,10 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0
 
 def parse(argv=None):
     p = argparse.ArgumentParser()
-    p.add_argument("--workload", choices=["vqvae", "transformer_lm"], default="vqvae",
+    p.add_argument("--workload", choices=["vqvae", "transformer_lm", "aux"], default="vqvae",
                    help="vqvae = the headline metric (BASELINE.json); transformer_lm = the SURVEY 8(f2) train step, reported "
-                        "in the same format under its own metric name")
+                        "in the same format under its own metric name; aux = the SURVEY 8(f1)/(f3)/(f4) paths (encode-only "
+                        "pass, STFT.inverse, monotonic alignment search), each with its roofline and its CPU leg")
     p.add_argument("--lm_batch", type=int, default=8, help="sequences per GPU (scripts/train_transformer_lm.sh: 8)")
     p.add_argument("--lm_len", type=int, default=258, help="tokens per sequence (<bos> + 256 codes + pad)")
     p.add_argument("--gpus", type=int, default=1)
@@ -229,6 +230,97 @@ def lm_main(args, rank, world, device, rehearsal):
         dist.destroy_process_group()
 
 
+def _timed(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(steps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / steps        # ms per call, on the launch stream
+
+
+def aux_main(args, device):
+    """`--workload aux`: the paths either side of the train step that SURVEY 8(f) names, single GPU.
+    (f1) encode-only pass of scripts/generate_vq_dataset.py (encoder + exact VQ search, no gradients): utterances/s;
+    (f3) STFT.inverse (datasets/transforms.py:125-156) at the dataset's analysis parameters: GB/s of algorithmic traffic;
+    (f4) GlowTTS maximum_path (models/glow_tts/submodules.py:28-67) at LJSpeech-like shapes: lattice cells/s.
+    CPU legs: the oracle restatements on this box's host cores (numpy / torch-CPU), bounded samples."""
+    import numpy as np
+    from smt_amd import native
+    native.lib()
+    from utils.commons import get_model
+    from datasets.transforms import STFT
+    from models.glow_tts.submodules import maximum_path
+    cores = usable_cpus()
+    torch.set_num_threads(cores)
+    out = {"metric": "auxiliary paths of SURVEY 8(f) (not the BASELINE.json headline)", "n_gpus": 1, "data": "synthetic",
+           "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None}
+    # ---- (f1) encode-only pass
+    cfg = make_config(args)
+    model, _ = get_model(cfg, device, 0)
+    model.eval()
+    pool = synthetic_batches(1, args.batch, args.clip_len, 0, device)
+    x, lens = pool[0][4], pool[0][5]
+    ms = _timed(lambda: model.encode_and_quantize(x, lens), args.steps, args.warmup)
+    out["encode_only"] = {"value": args.batch / ms * 1e3, "unit": "utterances/s", "ms_per_batch": ms, "dtype": cfg.model.get("compute_dtype", "fp32"),
+                          "config": {"workload": f"VQVAE.encode_and_quantize, {args.model}, batch {args.batch} x {args.clip_len} samples"}}
+    del model
+    # ---- (f3) STFT.inverse
+    b, n_fft, hop, frames = args.batch, 1024, 256, args.clip_len // 256 + 1
+    g = torch.Generator().manual_seed(3)
+    mag = torch.rand(b, n_fft // 2 + 1, frames, generator=g).to(device)
+    ph = ((torch.rand(b, n_fft // 2 + 1, frames, generator=g) - 0.5) * 6.28).to(device)
+    stft = STFT(n_fft=n_fft, hop_length=hop, win_length=n_fft, window="hann").to(device)
+    ms = _timed(lambda: stft.inverse(mag, ph), args.steps, args.warmup)
+    t_out = stft.inverse(mag, ph).shape[-1]
+    nbytes = 2 * mag.numel() * 4 + b * t_out * 4
+    leg = {}
+    if not args.no_cpu_baseline:
+        from oracle import vqvae_oracle as orc
+        m1, p1 = mag[:2].cpu(), ph[:2].cpu()
+        orc.stft_inverse(m1, p1, n_fft, hop, n_fft)
+        t0 = time.perf_counter()
+        orc.stft_inverse(m1, p1, n_fft, hop, n_fft)
+        dt = time.perf_counter() - t0
+        leg = {"value": 2 * (2 * m1[0].numel() * 4 + t_out * 4) / dt * 1e-9, "unit": "GB/s", "cores": cores, "kind": "port",
+               "sample": f"oracle stft_inverse, 2 clips of {frames} frames, one timed call {dt:.3f} s (includes rebuilding the "
+                         "pseudo-inverse basis, which the reference builds once in STFT.__init__)"}
+    out["stft_inverse"] = {"value": nbytes / ms * 1e-6, "unit": "GB/s", "ms_per_call": ms, "dtype": "f32",
+                           "roofline": {"bound": "hbm", "achieved": nbytes / ms * 1e-6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": nbytes / ms * 1e-6 / HBM_PEAK_GBS, "traffic": None},
+                           "config": {"workload": f"STFT.inverse n_fft {n_fft} hop {hop}, batch {b} x {frames} frames"},
+                           "cpu_baseline": leg or None}
+    # ---- (f4) monotonic alignment search
+    bb, t_x, t_y = 32, 160, 800
+    value = (torch.randn(bb, t_x, t_y, generator=g) * 3).to(device)
+    xl = torch.randint(t_x // 2, t_x + 1, (bb,), generator=g)
+    yl = torch.randint(t_y // 2, t_y + 1, (bb,), generator=g)
+    mask = ((torch.arange(t_x)[None, :, None] < xl[:, None, None]) & (torch.arange(t_y)[None, None, :] < yl[:, None, None])).float().to(device)
+    ms = _timed(lambda: maximum_path(value, mask), args.steps, args.warmup)
+    cells = bb * t_x * t_y
+    leg = {}
+    if not args.no_cpu_baseline:
+        from oracle import mas_oracle
+        v, m = value.cpu().numpy(), mask.cpu().numpy()
+        t0 = time.perf_counter()
+        ref = mas_oracle.maximum_path(v, m)
+        dt = time.perf_counter() - t0
+        same = bool(np.array_equal(ref, maximum_path(value, mask).cpu().numpy()))
+        leg = {"value": cells / dt, "unit": "cells/s", "cores": 1, "kind": "port",
+               "sample": f"oracle maximum_path (the reference's numpy algorithm) on the same batch, one call {dt:.3f} s; paths identical: {same}"}
+    out["maximum_path"] = {"value": cells / ms * 1e3, "unit": "cells/s", "ms_per_call": ms, "dtype": "f32",
+                           "roofline": {"bound": "hbm", "achieved": 12 * cells / ms * 1e-6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": 12 * cells / ms * 1e-6 / HBM_PEAK_GBS, "traffic": None,
+                                        "note": "latency-bound by construction: t_y sequential lattice columns with a barrier each; the "
+                                                "fraction is against the HBM bound its 12 B/cell would allow"},
+                           "config": {"workload": f"maximum_path batch {bb}, t_x {t_x}, t_y {t_y}, ragged"}, "cpu_baseline": leg or None}
+    print(json.dumps(out), flush=True)
+
+
 def launch_or_none(args, argv):
     """`python bench.py --gpus N` with N > 1 outside torchrun: start N rank processes of this script (fresh
     interpreters; this parent makes no HIP call) and return their exit code.  None = run in this process."""
@@ -295,6 +387,10 @@ def main(argv=None):
 
     if args.workload == "transformer_lm":
         return lm_main(args, rank, world, device, rehearsal)
+    if args.workload == "aux":
+        if world != 1:
+            sys.exit("bench.py --workload aux is a single-GPU measurement")
+        return aux_main(args, device)
 
     from smt_amd import native, profiler
     native.lib()  # fail loudly if the HIP library is missing

@@ -55,3 +55,12 @@ def test_transformer_lm_workload_line_and_two_rank_rehearsal():
     d2 = _run(["--gpus", "2"] + small, env={"SMT_BENCH_REHEARSAL": "1"})
     assert d2["n_gpus"] == 2 and d2["rehearsal_shared_gpu"] and d2["config"]["global_batch"] == 4
     assert abs(d2["value"] - 4 * 66 * 1000.0 / d2["ms_per_step"]) < 1e-6 * d2["value"]
+
+
+def test_aux_workload_reports_the_f_rows():
+    """`--workload aux`: encode-only pass, STFT.inverse and maximum_path, each with a value, a unit and (where it has a
+    byte count) a roofline object."""
+    d = _run(["--workload", "aux", "--batch", "2", "--clip_len", "16384", "--steps", "2", "--warmup", "1", "--no_cpu_baseline"])
+    assert d["encode_only"]["unit"] == "utterances/s" and d["encode_only"]["value"] > 0
+    assert d["stft_inverse"]["roofline"]["bound"] == "hbm" and 0 < d["stft_inverse"]["roofline"]["frac"] < 1
+    assert d["maximum_path"]["unit"] == "cells/s" and d["maximum_path"]["value"] > 0 and d["vs_baseline"] is None

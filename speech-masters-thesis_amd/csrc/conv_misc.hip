@@ -56,11 +56,24 @@ __global__ __launch_bounds__(256) void gate_mix_fwd_kernel(const T* __restrict__
 // holds two operand vectors instead of 2*depth of them: 4x the lanes in flight at a third of the
 // registers -- this is an HBM-latency-bound kernel.  depth must be a power of two <= 8 and
 // depth * (w / EPV) a divisor of 64 (w = 64: 32 lanes per row, two rows per wave).
-template <typename T>
+// lane ^ 8 inside a 16-lane row = rotate the row by 8 (DPP row_ror:8); lane ^ 16 = ds_swizzle in bit mode (xor mask 0x10):
+// neither needs an address register or an LDS access slot like ds_bpermute
+__device__ __forceinline__ float gm_xor8(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float gm_xor16(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+}
+
+// VPR / DEPTH > 0 fix the geometry at compile time (the shuffle distances become constants: DPP / swizzle instead of
+// ds_bpermute with computed addresses, loops unrolled); 0 = take them from the arguments.
+template <typename T, int VPR = 0, int DEPTH = 0>
 __global__ __launch_bounds__(256) void gate_mix_bwd_kernel(const T* __restrict__ z, const T* __restrict__ dg,
-                                                           T* __restrict__ dz, long long rows, int w, int depth,
+                                                           T* __restrict__ dz, long long rows, int w_, int depth_,
                                                            int ldz, int ldg, int lddz) {
   constexpr int EPV = Tr<T>::EPV;
+  const int w = VPR > 0 ? VPR * EPV : w_;
+  const int depth = DEPTH > 0 ? DEPTH : depth_;
   const int vpr = w / EPV;                 // channel vectors per row
   const int lpr = vpr * depth;             // lanes per row (a power of two dividing 64)
   const long long total = rows * lpr;
@@ -92,11 +105,19 @@ __global__ __launch_bounds__(256) void gate_mix_bwd_kernel(const T* __restrict__
     Vec<T, EPV> dt, ds;
 #pragma unroll
     for (int e = 0; e < EPV; ++e) {
-      float m = sx[e];
-      for (int o = vpr; o < lpr; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-      const float ex = __expf(sx[e] - m);
-      float den = ex, dot = ex * th[e];
-      for (int o = vpr; o < lpr; o <<= 1) { den += __shfl_xor(den, o, 64); dot += __shfl_xor(dot, o, 64); }
+      float m = sx[e], ex, den, dot;
+      if constexpr (VPR == 8 && DEPTH == 4) {      // branch d sits 8 d lanes away: xor 8 is a DPP row rotation, xor 16 a swizzle
+        m = fmaxf(m, gm_xor8(m)); m = fmaxf(m, gm_xor16(m));
+        ex = __expf(sx[e] - m);
+        den = ex; dot = ex * th[e];
+        den += gm_xor8(den); dot += gm_xor8(dot);
+        den += gm_xor16(den); dot += gm_xor16(dot);
+      } else {
+        for (int o = vpr; o < lpr; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        ex = __expf(sx[e] - m);
+        den = ex; dot = ex * th[e];
+        for (int o = vpr; o < lpr; o <<= 1) { den += __shfl_xor(den, o, 64); dot += __shfl_xor(dot, o, 64); }
+      }
       // bf16 results: one reciprocal (1 ulp) instead of two IEEE divisions; the fp32 parity path keeps the divisions
       float sm;
       if constexpr (sizeof(T) == 2) {
@@ -380,7 +401,10 @@ extern "C" int smt_gate_mix_bwd(const void* z, const void* dg, void* dz, int dty
   SMT_CHECK_ARG((depth & (depth - 1)) == 0 && lpr <= 64 && 64 % lpr == 0 && ((width / epv) & (width / epv - 1)) == 0,
                 "smt_gate_mix_bwd: depth and width/%d must be powers of two with depth*width/%d <= 64", epv, epv);
   unsigned grid = ew_grid(rows * lpr);
-  if (dtype == SMT_BF16)
+  if (dtype == SMT_BF16 && width == 64 && depth == 4)      // the reference configuration: four branches of width 64
+    gate_mix_bwd_kernel<__bf16, 8, 4><<<grid, 256, 0, stream>>>((const __bf16*)z, (const __bf16*)dg, (__bf16*)dz, rows, width,
+                                                               depth, ld_z, ld_g, ld_dz);
+  else if (dtype == SMT_BF16)
     gate_mix_bwd_kernel<__bf16><<<grid, 256, 0, stream>>>((const __bf16*)z, (const __bf16*)dg, (__bf16*)dz, rows, width,
                                                          depth, ld_z, ld_g, ld_dz);
   else

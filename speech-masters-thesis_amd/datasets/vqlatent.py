@@ -62,24 +62,22 @@ class VQLatent(Dataset):
         return len(self.pkl_files)
 
     def __getitem__(self, index):
-        pkl = load_plain_pickle(os.path.join(self.dataset_path, self.split, self.pkl_files[index]))
-        audio, token = pkl["x"], pkl["q"]
-        speaker = torch.tensor((pkl["speaker"],), dtype=torch.long) if "speaker" in pkl else None
+        item = load_plain_pickle(os.path.join(self.dataset_path, self.split, self.pkl_files[index]))
+        samples, codes = item["x"], item["q"]
+        speaker = torch.tensor((item["speaker"],), dtype=torch.long) if "speaker" in item else None
         if self.remove_consecutive:
-            token = [t[0] for t in groupby(token)]
-        cf = self.metadata["compression_factor"]
-        if self.segment_length > 0 and len(token) > self.segment_length:
-            start = random.randint(0, len(token) - self.segment_length)
-            token = token[start:start + self.segment_length]
-            audio = audio[start * cf:start * cf + self.segment_length * cf]      # audio is cf times longer
-        # <bos> in front; every code shifted by OFFSET (BOS - OFFSET + OFFSET == BOS)
-        token = torch.tensor([VQLatent.BOS - VQLatent.OFFSET] + list(token), dtype=torch.long).flatten() + VQLatent.OFFSET
-        audio = torch.tensor(audio, dtype=torch.float32).flatten()
-        token_len, audio_len = token.shape[-1], audio.shape[-1]
-        if self.segment_length > 0:       # short examples are padded to the segment (vqlatent.py:95-98)
-            token = F.pad(token, (0, self.segment_length + 2 - len(token)), mode="constant", value=VQLatent.PAD)
-            audio = F.pad(audio, (0, self.segment_length * cf - len(audio)))
-        spect = spect_len = None
+            codes = [run[0] for run in groupby(codes)]
+        ratio, seg = self.metadata["compression_factor"], self.segment_length      # samples per code, codes per segment
+        if 0 < seg < len(codes):
+            first = random.randint(0, len(codes) - seg)                           # one window over codes and samples alike
+            codes, samples = codes[first:first + seg], samples[first * ratio:(first + seg) * ratio]
+        # <bos> in front; every code moves up by OFFSET so that 0 / 1 stay <pad> / <bos>
+        token = torch.tensor([VQLatent.BOS] + [q + VQLatent.OFFSET for q in codes], dtype=torch.long)
+        audio = torch.tensor(samples, dtype=torch.float32).reshape(-1)
+        token_len, audio_len = token.numel(), audio.numel()
+        if seg > 0:                                                               # short items fill up the segment (vqlatent.py:95-98)
+            token = F.pad(token, (0, seg + 2 - token_len), value=VQLatent.PAD)
+            audio = F.pad(audio, (0, seg * ratio - audio_len))
         if self.use_spect:
             raise NotImplementedError("use_spect: log-mel is computed on the device by datasets.transforms."
                                       "MelSpectrogram, not inside DataLoader workers")
@@ -87,25 +85,24 @@ class VQLatent(Dataset):
             audio = audio_len = None
         if not self.use_token:
             token = token_len = None
-        return token, token_len, spect, spect_len, audio, audio_len, speaker
+        return token, token_len, None, None, audio, audio_len, speaker
 
     @staticmethod
     def collate(batch):
-        """None entries are slots the config does not need (vqlatent.py:114-142)."""
+        """Slots the config does not need stay None (vqlatent.py:114-142); the others are right-padded to the longest item."""
+        def pad_stack(items, fill):
+            width = max(t.shape[-1] for t in items)
+            return torch.stack([F.pad(t, (0, width - t.shape[-1]), value=fill) for t in items], dim=0)
+
         token, token_len, spect, spect_len, audio, audio_len, speaker = zip(*batch)
         out = [None] * 7
-        if token[0] is not None:
-            out[1] = torch.tensor(token_len, dtype=torch.long)
-            longest = max(x.shape[-1] for x in token)
-            out[0] = torch.stack([F.pad(x, (0, longest - x.shape[-1]), value=VQLatent.PAD) for x in token], dim=0)
-        if spect[0] is not None:
-            out[3] = torch.tensor(spect_len, dtype=torch.long)
-            longest = max(x.shape[-1] for x in spect)
-            out[2] = torch.stack([F.pad(x, (0, longest - x.shape[-1]), value=math.log(1e-7)) for x in spect], dim=0)
-        if audio[0] is not None:
-            out[5] = torch.tensor(audio_len, dtype=torch.long)
-            longest = max(x.shape[-1] for x in audio)
-            out[4] = torch.stack([F.pad(x, (0, longest - x.shape[-1])) for x in audio], dim=0).unsqueeze(1)
+        for slot, items, lens, fill in ((0, token, token_len, VQLatent.PAD), (2, spect, spect_len, math.log(1e-7)),
+                                        (4, audio, audio_len, 0.0)):
+            if items[0] is not None:
+                out[slot] = pad_stack(items, fill)
+                out[slot + 1] = torch.tensor(lens, dtype=torch.long)
+        if out[4] is not None:
+            out[4] = out[4].unsqueeze(1)
         if speaker[0] is not None:
             out[6] = torch.stack(speaker, dim=0)
         return tuple(out)

@@ -656,22 +656,38 @@ __global__ __launch_bounds__(256) void vq_backward_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------- EMA -------
-// One wave per row; 256 contiguous bytes per atomic wave-instruction (the shape the
-// memory-side f32 atomic unit runs at full rate).
+// _k_sum = onehot^T x, _k_elem = column sums of onehot (bottleneck.py:64-68) as a scatter-add.  The sums are accumulated
+// in 64-bit FIXED POINT (2^-24 units) with integer atomics: integer addition is associative, so the result does not
+// depend on the order in which rows arrive -- bit-reproducible from run to run, which f32 atomics are not -- and is
+// converted to f32 once at the end.  A value is exact when it is a multiple of 2^-24 below 2^15 in magnitude (every bf16
+// and every f32 encoder output of ordinary size); larger magnitudes saturate at +-2^39 units so that 2^23 rows cannot
+// overflow the accumulator.  One wave per row; 512 contiguous bytes per atomic wave-instruction.
+constexpr float VQ_FX_SCALE = 16777216.f;            // 2^24
+constexpr float VQ_FX_LIMIT = 549755813888.f;        // 2^39
 __global__ __launch_bounds__(256) void vq_ema_accumulate_kernel(const float* __restrict__ x,
                                                                 const long long* __restrict__ idx,
                                                                 const float* __restrict__ row_mask, long long N, int K,
-                                                                int D, float* __restrict__ stats) {
+                                                                int D, unsigned long long* __restrict__ acc) {
   const int lane = threadIdx.x & 63;
   const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
   for (long long row = wave0; row < N; row += nwaves) {
     if (row_mask && row_mask[row] == 0.f) continue;
     const long long code = idx[row];
-    float* dst = stats + (size_t)code * D;
-    for (int i = lane; i < D; i += 64) atomicAdd(dst + i, x[row * D + i]);
-    if (lane == 0) atomicAdd(stats + (size_t)K * D + code, 1.0f);
+    unsigned long long* dst = acc + (size_t)code * D;
+    for (int i = lane; i < D; i += 64) {
+      const float v = fminf(fmaxf(x[row * D + i] * VQ_FX_SCALE, -VQ_FX_LIMIT), VQ_FX_LIMIT);
+      atomicAdd(dst + i, (unsigned long long)__float2ll_rn(v));          // two's complement: the unsigned add is the signed add
+    }
+    if (lane == 0) atomicAdd(acc + (size_t)K * D + code, 1ull);
   }
+}
+__global__ __launch_bounds__(256) void vq_ema_convert_kernel(const unsigned long long* __restrict__ acc, float* __restrict__ stats,
+                                                             int n_sums, int n_total) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_total) return;
+  const long long v = (long long)acc[e];
+  stats[e] = e < n_sums ? (float)((double)v * (1.0 / 16777216.0)) : (float)v;
 }
 
 // EMA mix + revival for VQ_PART codes per workgroup (bottleneck.py:78-84); leaves the partial column sums of the NEW
@@ -840,15 +856,25 @@ extern "C" int smt_vq_backward(const float* x, const float* x_d, const float* ro
   return 0;
 }
 
-extern "C" int smt_vq_ema_accumulate(const float* x, const int64_t* idx, const float* row_mask, int64_t n_rows,
-                                     int k_bins, int dim, float* stats, smt_stream_t stream_) {
+extern "C" size_t smt_vq_ema_accumulate_workspace_bytes(int k_bins, int dim) {
+  return ((size_t)k_bins * dim + k_bins) * sizeof(unsigned long long);
+}
+
+extern "C" int smt_vq_ema_accumulate(const float* x, const int64_t* idx, const float* row_mask, int64_t n_rows, int k_bins,
+                                     int dim, float* stats, void* workspace, size_t workspace_bytes, smt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  SMT_CHECK_ARG(stats && (n_rows == 0 || (x && idx)), "smt_vq_ema_accumulate: null pointer");
-  (void)hipMemsetAsync(stats, 0, ((size_t)k_bins * dim + k_bins) * sizeof(float), stream);
-  if (n_rows == 0) return 0;
-  unsigned grid = (unsigned)min((long long)4096, (n_rows * 64 + 255) / 256);
-  vq_ema_accumulate_kernel<<<grid, 256, 0, stream>>>(x, (const long long*)idx, row_mask, n_rows, k_bins, dim, stats);
-  SMT_CHECK_LAUNCH("vq_ema_accumulate");
+  SMT_CHECK_ARG(stats && workspace && (n_rows == 0 || (x && idx)), "smt_vq_ema_accumulate: null pointer");
+  SMT_CHECK_ARG(workspace_bytes >= smt_vq_ema_accumulate_workspace_bytes(k_bins, dim), "smt_vq_ema_accumulate: workspace too small");
+  const int n_sums = k_bins * dim, n_total = n_sums + k_bins;
+  unsigned long long* acc = (unsigned long long*)workspace;
+  (void)hipMemsetAsync(acc, 0, (size_t)n_total * sizeof(unsigned long long), stream);
+  if (n_rows > 0) {
+    unsigned grid = (unsigned)min((long long)4096, (n_rows * 64 + 255) / 256);
+    vq_ema_accumulate_kernel<<<grid, 256, 0, stream>>>(x, (const long long*)idx, row_mask, n_rows, k_bins, dim, acc);
+    SMT_CHECK_LAUNCH("vq_ema_accumulate");
+  }
+  vq_ema_convert_kernel<<<(n_total + 255) / 256, 256, 0, stream>>>(acc, stats, n_sums, n_total);
+  SMT_CHECK_LAUNCH("vq_ema_convert");
   return 0;
 }
 

@@ -137,6 +137,30 @@ def test_ema_accumulate_matches_dense_onehot():
     ref_sum = torch.zeros(kb, d, dtype=torch.float64).index_add_(0, idx[sel], x[sel].double())
     ref_cnt = torch.bincount(idx[sel], minlength=kb).double()
     got = stats.cpu().double()
-    # f32 atomics: order-dependent rounding, ~40 adds per code -> 1e-5 abs on sums of O(10)
-    assert torch.allclose(got[:kb * d].view(kb, d), ref_sum, atol=2e-5)
+    # 64-bit fixed-point accumulation (2^-24 units): each addend is rounded once by <= 2^-25, ~40 addends per code, then one
+    # rounding to f32 -> 4e-6 abs on sums of O(10)
+    assert torch.allclose(got[:kb * d].view(kb, d), ref_sum, atol=4e-6)
     assert torch.equal(got[kb * d:kb * d + kb], ref_cnt)
+    # integer atomics are order-independent: the statistics are bit-identical from run to run, and for any row order
+    again = torch.empty_like(stats)
+    live = kb * d + kb                                   # sums and counts (the rest of the buffer is the revival rows' slot)
+    vq.ema_accumulate(x.cuda(), idx.cuda(), mask.cuda(), kb, again)
+    assert torch.equal(again[:live], stats[:live])
+    perm = torch.randperm(n, generator=g)
+    vq.ema_accumulate(x[perm].cuda(), idx[perm].cuda(), mask[perm].cuda(), kb, again)
+    assert torch.equal(again[:live], stats[:live])
+    # rows on the 2^-24 grid (here multiples of 2^-8) are represented exactly: the sums equal the exact ones rounded once
+    xb = torch.round(x * 256.0) / 256.0
+    vq.ema_accumulate(xb.cuda(), idx.cuda(), mask.cuda(), kb, again)
+    exact = torch.zeros(kb, d, dtype=torch.float64).index_add_(0, idx[sel], xb[sel].double())
+    assert torch.equal(again[:kb * d].view(kb, d).cpu(), exact.float())
+
+
+def test_ema_accumulate_saturates_instead_of_overflowing():
+    from smt_amd import vq
+    x = torch.tensor([[3.0e6, -3.0e6, 1.0, 0.0] + [0.0] * 28] * 4)
+    idx = torch.zeros(4, dtype=torch.long)
+    stats = torch.empty(vq.ema_stats_numel(2, 32), device="cuda")
+    vq.ema_accumulate(x.cuda(), idx.cuda(), None, 2, stats)
+    got = stats.cpu()
+    assert got[0] == 4 * 32768.0 and got[1] == -4 * 32768.0 and got[2] == 4.0 and got[64] == 4.0 and got[65] == 0.0

@@ -1406,18 +1406,22 @@ __global__ __launch_bounds__(K1_NT) void conv_k1act_kernel(ConvArgs p, const __b
       }
       const int t = t0 + row;
       const float keep_row = (t >= len_out) ? 0.f : 1.f;
+      // dropout hash input of element pair (g, k): ((rowbase + cs + 8 g + k) >> 1) * C + key.  rowbase, cs, 8 g and k are
+      // all even (site_width % 32 == 0), so the shift distributes and the product is linear mod 2^32: ONE quarter-rate
+      // multiply per (row, column block) instead of eight, the rest are adds of compile-time multiples of C
+      const unsigned rowhalf = (unsigned)((((unsigned long long)b * p.Ty + t) * p.site_width) >> 1);
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         unsigned up[8];
+        const unsigned hbase = (rowhalf + (unsigned)(cs[c] >> 1)) * 0x9E3779B1u + keys[c];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const unsigned long long base = ((unsigned long long)b * p.Ty + t) * p.site_width + (cs[c] + 8 * g);
           float o[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) o[k] = (float)(T)(acc[c][4 * g + k] + bval[c][4 * g + k]) * keep_row;
 #pragma unroll
           for (int k = 0; k < 4; k += 2) {
-            const unsigned h = fmix32((unsigned)((base + k) >> 1) * 0x9E3779B1u + keys[c]);
+            const unsigned h = fmix32(hbase + (unsigned)(4 * g + (k >> 1)) * 0x9E3779B1u);
             const bool k0 = (h & 0xFFFFu) >= p.drop_thresh16, k1 = (h >> 16) >= p.drop_thresh16;
             up[2 * g + (k >> 1)] = pack_bf16x2((k0 && o[k] > 0.f) ? o[k] * p.drop_scale : 0.f,
                                                (k1 && o[k + 1] > 0.f) ? o[k + 1] * p.drop_scale : 0.f);

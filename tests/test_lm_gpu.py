@@ -402,3 +402,62 @@ def test_forward_with_no_scored_position_is_nan_like_the_reference(tmp_path):
     model.train()
     out, metrics = model(x.to(DEV), torch.tensor([1, 1]).to(DEV), None, None)
     assert math.isnan(float(out["loss"])) and math.isnan(float(metrics["accuracy"]))
+
+
+# ------------------------------------------------------------------------------------------------ full-size properties
+def test_full_size_causality_padding_and_batch_independence(tmp_path):
+    """Size-independent properties at the reference's configuration (12 x d512, batch 8 x 258), eval mode, bit-exact:
+    (1) causality -- tokens after position t cannot change the logits up to t; (2) key padding -- tokens at or beyond
+    lens[b] cannot change the logits before lens[b], nor the loss; (3) a batch item's logits do not depend on its batch mates
+    or its slot (to 2e-5: library GEMMs).  Masked scores enter the softmax as exactly zero weights, so (1) and (2) hold bit
+    for bit, not to a tolerance."""
+    model, _ = _build(tmp_path)
+    p32 = lmo.init_params(512, 512, 16, 2048, 12, seed=61)
+    model.load_state_dict(p32, strict=False)
+    model.eval()
+    x, lens = lmo.synthetic_tokens(8, 258, 512, seed=62)
+    xd, ld = x.to(DEV), lens.to(DEV, torch.int32)
+    with torch.no_grad():
+        base = model.logits(xd, ld)
+        # (1) change every token after position 100 (keeping them real codes)
+        x2 = xd.clone()
+        x2[:, 101:] = (x2[:, 101:] + 7 - lmo.OFFSET) % 512 + lmo.OFFSET
+        assert torch.equal(model.logits(x2, ld)[:, :101], base[:, :101])
+        # (2) scribble over the padding
+        x3 = xd.clone()
+        pad = torch.arange(258, device=DEV)[None, :] >= ld[:, None]
+        x3[pad] = 5
+        out3 = model.logits(x3, ld)
+        for b in range(8):
+            n = int(lens[b])
+            assert torch.equal(out3[b, :n], base[b, :n])
+        # (3) reverse the batch, and run one item alone: equal up to the library GEMM's row tiling (hipBLASLt picks its
+        # accumulation order by row position and problem size), our kernels treat every (batch, head) alike
+        rev = torch.arange(7, -1, -1, device=DEV)
+        assert torch.allclose(model.logits(xd[rev], ld[rev])[rev], base, atol=2e-5)
+        assert torch.allclose(model.logits(xd[3:4], ld[3:4])[0], base[3], atol=2e-5)
+    loss_a, _ = model(xd, lens.to(DEV), None, None)
+    x4 = xd.clone()
+    x4[pad] = lmo.PAD                                    # what the dataset writes there
+    loss_b, _ = model(x4, lens.to(DEV), None, None)
+    assert torch.equal(loss_a["loss"], loss_b["loss"])
+
+
+def test_full_size_attention_is_linear_in_the_values():
+    """softmax(QK^T) V is linear in V: attention(q, k, a v1 + v2) == a attention(q, k, v1) + attention(q, k, v2) up to f32
+    rounding, at 8 x 16 heads x 258 with ragged lengths and dropout ON (the mask depends on positions only)."""
+    from smt_amd import lm as K
+    g = torch.Generator().manual_seed(5)
+    b, l, h = 8, 258, 16
+    qk = torch.randn(b, l, 2 * h * 32, generator=g).to(DEV)
+    v1, v2 = torch.randn(b, l, h * 32, generator=g).to(DEV), torch.randn(b, l, h * 32, generator=g).to(DEV)
+    lens = torch.randint(100, l + 1, (b,), generator=g).to(DEV, torch.int32)
+    drop = K.Drop(0.1, True, 9, 4)
+
+    def att(v):
+        return K.attention(torch.cat([qk, v], dim=-1), lens, h, True, drop)
+
+    lhs, rhs = att(2.0 * v1 + v2), 2.0 * att(v1) + att(v2)
+    assert torch.allclose(lhs, rhs, atol=2e-5) and float(lhs.abs().max()) > 0.1
+    # scaling V by a power of two scales the context exactly
+    assert torch.equal(att(4.0 * v1), 4.0 * att(v1))

@@ -118,6 +118,28 @@ __device__ __forceinline__ void at_merge_store(float* red, const f32x16v& o, flo
   __syncthreads();
 }
 
+// Dropout factors of the 16 accumulator elements of a lane whose element i stands for linear index e_first + at_acc_row(i, hh)
+// (consecutive in groups of four).  Two consecutive indices 2 j, 2 j + 1 share one hash (smt_hip.h "dropout"), so when
+// e_first is even -- always, if the row length L is even -- one hash serves two elements: 8 hashes instead of 16.
+__device__ __forceinline__ void at_keep16(float (&kf)[16], unsigned long long e_first, int hh, unsigned key, unsigned thr,
+                                          float dscale) {
+  if (thr == 0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kf[i] = 1.f;
+  } else if ((e_first & 1ull) == 0) {
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+      const unsigned h = fmix32((unsigned)((e_first + at_acc_row(i, hh)) >> 1) * 0x9E3779B1u + key);
+      kf[i] = (h & 0xFFFFu) >= thr ? dscale : 0.f;
+      kf[i + 1] = (h >> 16) >= thr ? dscale : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kf[i] = drop_keep(e_first + at_acc_row(i, hh), key, thr) ? dscale : 0.f;
+  }
+}
+constexpr float LM_LOG2E = 1.4426950408889634f;
+
 __global__ __launch_bounds__(256) void lm_attn_fwd_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
                                                           float* __restrict__ ctx, float* __restrict__ lse, int L, int H,
                                                           int causal, unsigned key, unsigned thr, float dscale) {
@@ -134,7 +156,7 @@ __global__ __launch_bounds__(256) void lm_attn_fwd_kernel(const float* __restric
   const int q0 = qb * 32, qi = q0 + col, qc = min(qi, L - 1);
   const int kend = causal ? min(len, min(L, q0 + 32)) : len;  // keys any query of this block can see
   float qf[16];
-  at_row_frag(qf, qm, pitch, qi, L - 1, hh, rsqrtf((float)LM_DH));
+  at_row_frag(qf, qm, pitch, qi, L - 1, hh, rsqrtf((float)LM_DH) * LM_LOG2E);   // scores in base-2 units: exp2 is ONE instruction
   f32x16v o = at_zero16();
   float m = -INFINITY, z = 0.f;
   const unsigned long long e0 = (((unsigned long long)b * H + h) * L + qc) * L;
@@ -144,25 +166,31 @@ __global__ __launch_bounds__(256) void lm_attn_fwd_kernel(const float* __restric
     at_col_frag(vf, vm, pitch, k0, L - 1, col, hh);
     f32x16v st = at_mfma16(kf, qf, at_zero16());
     float mloc = -INFINITY;
+    if (k0 + 32 <= kend && (!causal || k0 + 31 <= q0)) {      // uniform: every key of the block visible to every query
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int kj = k0 + at_acc_row(i, hh);
-      st[i] = (kj < kend && (!causal || kj <= qi)) ? st[i] : -INFINITY;
-      mloc = fmaxf(mloc, st[i]);
+      for (int i = 0; i < 16; ++i) mloc = fmaxf(mloc, st[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int kj = k0 + at_acc_row(i, hh);
+        st[i] = (kj < kend && (!causal || kj <= qi)) ? st[i] : -INFINITY;
+        mloc = fmaxf(mloc, st[i]);
+      }
     }
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
     const float mn = fmaxf(m, mloc), ms = (mn == -INFINITY) ? 0.f : mn;
-    const float corr = __expf(m - ms);                        // m = -inf: 0
+    const float corr = __builtin_amdgcn_exp2f(m - ms);        // m = -inf: 0
     z *= corr;
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[i] *= corr;
     m = mn;
     float pk[16];
+    at_keep16(pk, e0 + k0, hh, key, thr, dscale);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const float p = __expf(st[i] - ms);                     // masked: exp(-inf) = 0
+      const float p = __builtin_amdgcn_exp2f(st[i] - ms);     // masked: exp2(-inf) = 0
       z += p;
-      pk[i] = p * lm_keep(e0 + k0 + at_acc_row(i, hh), key, thr, dscale);
+      pk[i] *= p;
     }
     o = at_mfma16(vf, pk, o);
   }
@@ -172,12 +200,14 @@ __global__ __launch_bounds__(256) void lm_attn_fwd_kernel(const float* __restric
   const float mm = fmaxf(fmaxf(red_m[0][lane], red_m[1][lane]), fmaxf(red_m[2][lane], red_m[3][lane]));
   float zz = 0.f;
 #pragma unroll
-  for (int k = 0; k < AT_W; ++k) zz += red_m[k][lane] == -INFINITY ? 0.f : red_z[k][lane] * __expf(red_m[k][lane] - mm);
+  for (int k = 0; k < AT_W; ++k)
+    zz += red_m[k][lane] == -INFINITY ? 0.f : red_z[k][lane] * __builtin_amdgcn_exp2f(red_m[k][lane] - mm);
   zz += __shfl_xor(zz, 32, 64);
   const bool any = mm != -INFINITY;                           // at least one visible key
-  at_merge_store(red, o, (m == -INFINITY) ? 0.f : __expf(m - mm), w, lane, hh, any ? 1.f / zz : 0.f, qi < L,
+  at_merge_store(red, o, (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - mm), w, lane, hh, any ? 1.f / zz : 0.f, qi < L,
                  ctx + ((size_t)b * L + qc) * d + h * LM_DH);
-  if (w == 0 && hh == 0 && qi < L) lse[((size_t)b * H + h) * L + qi] = any ? mm + __logf(zz) : 0.f;
+  // lse is kept in BASE-2 units (log2 of the sum of 2^score): it is scratch between this kernel and the backward ones
+  if (w == 0 && hh == 0 && qi < L) lse[((size_t)b * H + h) * L + qi] = any ? mm + __builtin_amdgcn_logf(zz) : 0.f;
 }
 
 // Backward: P_ij = exp(s_ij - lse_i); dPd_ij = dctx_i . v_j; delta_i = sum_j P_ij keep_ij dPd_ij = dctx_i . ctx_i;
@@ -202,7 +232,7 @@ __global__ __launch_bounds__(256) void lm_attn_dq_kernel(const float* __restrict
   const int kend = causal ? min(len, min(L, q0 + 32)) : len;
   const float sc = rsqrtf((float)LM_DH);
   float qf[16], gf[16];
-  at_row_frag(qf, qm, pitch, qi, L - 1, hh, sc);
+  at_row_frag(qf, qm, pitch, qi, L - 1, hh, sc * LM_LOG2E);    // base-2 scores, as in the forward (lse is base-2)
   at_row_frag(gf, dctx + (size_t)b * L * d + h * LM_DH, d, qi, L - 1, hh, 1.f);
   float dl = 0.f;
   {
@@ -224,11 +254,17 @@ __global__ __launch_bounds__(256) void lm_attn_dq_kernel(const float* __restrict
     const f32x16v st = at_mfma16(kf, qf, at_zero16());
     const f32x16v dp = at_mfma16(vf, gf, at_zero16());
     float ds[16];
+    at_keep16(ds, e0 + k0, hh, key, thr, dscale);
+    if (k0 + 32 <= kend && (!causal || k0 + 31 <= q0)) {      // uniform: no mask inside the block
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int kj = k0 + at_acc_row(i, hh);
-      const float p = (kj < kend && (!causal || kj <= qi)) ? __expf(st[i] - li) : 0.f;
-      ds[i] = p * (lm_keep(e0 + kj, key, thr, dscale) * dp[i] - dl);
+      for (int i = 0; i < 16; ++i) ds[i] = __builtin_amdgcn_exp2f(st[i] - li) * (ds[i] * dp[i] - dl);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int kj = k0 + at_acc_row(i, hh);
+        const float p = (kj < kend && (!causal || kj <= qi)) ? __builtin_amdgcn_exp2f(st[i] - li) : 0.f;
+        ds[i] = p * (ds[i] * dp[i] - dl);
+      }
     }
     dq = at_mfma16(kc, ds, dq);
   }
@@ -254,7 +290,7 @@ __global__ __launch_bounds__(256) void lm_attn_dkv_kernel(const float* __restric
   const int kj = kb * 32 + col, kc = min(kj, L - 1);
   const float sc = rsqrtf((float)LM_DH);
   float kf[16], vf[16];
-  at_row_frag(kf, qm + d, pitch, kj, L - 1, hh, sc);           // 1/sqrt(dh) folded into the key
+  at_row_frag(kf, qm + d, pitch, kj, L - 1, hh, sc * LM_LOG2E); // 1/sqrt(dh) and the base-2 conversion folded into the key
   at_row_frag(vf, qm + 2 * d, pitch, kj, L - 1, hh, 1.f);
   f32x16v dk = at_zero16(), dv = at_zero16();
   const unsigned long long e0 = ((unsigned long long)b * H + h) * L;
@@ -271,7 +307,7 @@ __global__ __launch_bounds__(256) void lm_attn_dkv_kernel(const float* __restric
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int qr = q0 + at_acc_row(i, hh), qrc = min(qr, L - 1);
-        const float p = (qr < L && kj < len && (!causal || kj <= qr)) ? __expf(st[i] - lrow[qrc]) : 0.f;
+        const float p = (qr < L && kj < len && (!causal || kj <= qr)) ? __builtin_amdgcn_exp2f(st[i] - lrow[qrc]) : 0.f;
         pk[i] = p * lm_keep((e0 + qrc) * L + kc, key, thr, dscale);
         ds[i] = pk[i] * dp[i] - p * drow[qrc];
       }

@@ -39,6 +39,9 @@ def parse(argv=None):
                         "pass, STFT.inverse, monotonic alignment search), each with its roofline and its CPU leg")
     p.add_argument("--lm_batch", type=int, default=8, help="sequences per GPU (scripts/train_transformer_lm.sh: 8)")
     p.add_argument("--lm_len", type=int, default=258, help="tokens per sequence (<bos> + 256 codes + pad)")
+    p.add_argument("--lm_graph", action="store_true",
+                   help="transformer_lm workload: replay forward + backward as one captured hipGraph (smt_amd/graph.py; single "
+                        "GPU; no per-kernel events inside a graph)")
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=3)
@@ -168,9 +171,18 @@ def lm_main(args, rank, world, device, rehearsal):
         x[:, 0], x[:, -1] = 1, 0
         pool.append((x.to(device), torch.full((args.lm_batch,), args.lm_len - 1).to(device)))
     model.train()
+    graphed = None
+    if args.lm_graph:
+        if world != 1:
+            sys.exit("bench.py --lm_graph is a single-GPU mode (the gradient exchange is issued from autograd hooks)")
+        from smt_amd.graph import GraphedTrainStep
+        graphed = GraphedTrainStep(model, optimizer, scheduler, pool[0][0], pool[0][1])
+        args.no_kernel_events = True
 
     def step(i):
         x, lens = pool[i % len(pool)]
+        if graphed is not None:
+            return graphed.step(x, lens)
         if grad_sync is not None:
             grad_sync.zero_grad()                 # gradients live in the flat all-reduce buffer
         else:
@@ -218,7 +230,7 @@ def lm_main(args, rank, world, device, rehearsal):
                 "value": args.lm_batch * args.lm_len * world * args.steps / elapsed, "unit": "tokens/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "rehearsal_shared_gpu": bool(rehearsal),
+                "rehearsal_shared_gpu": bool(rehearsal), "hip_graph": bool(args.lm_graph),
                 "config": {"workload": "models/transformer_lm (12 x d512, 16 heads, ff 2048, dropout 0.1, CE), "
                                        f"batch {args.lm_batch}/GPU x {args.lm_len} tokens, fp32, AdamW",
                            "global_batch": args.lm_batch * world, "seq_len": args.lm_len, "parallelism": f"dp{world}"},

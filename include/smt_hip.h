@@ -321,15 +321,21 @@ int smt_stft_inverse(const float* magnitude, const float* phase, const float* wi
  * (models/transformer_lm/transformer_lm.py:32-135: nn.TransformerEncoder, post-norm layers, ReLU feed-forward).
  * Activations are batch-major rows [batch, len, dim] f32 (the reference runs them [len, batch, dim]; the layout is
  * internal to the model).  Every dropout site uses the counter-based generator above on the element's linear index
- * in the tensor being dropped; thresh16 = 0 disables it (eval). */
+ * in the tensor being dropped; thresh16 = 0 disables it (eval).  Every entry takes the site key twice: `drop_key` by value
+ * and `drop_key_dev`, a DEVICE pointer to one key that overrides it when non-NULL -- a captured hipGraph freezes by-value
+ * arguments, so a graphed step keeps its keys in device memory and refreshes them with smt_lm_make_keys. */
+
+/* keys_dev[s] = fmix32(seed_dev[0] * 0x9E3779B1 + s * 0x7F4A7C15 + 1), s < n_sites: the per-site keys of the step whose
+ * seed is in device memory (the same derivation the host uses for `drop_key`). */
+int smt_lm_make_keys(const uint32_t* seed_dev, uint32_t* keys_dev, int n_sites, smt_stream_t stream);
 
 /* out = (emb[tokens] * mul + pe[position]) * keep   (transformer_lm.py:114-116, PositionalEncoding :27-29);
  * tokens [batch, len] int64, emb [vocab_rows, dim], pe [>= len, dim].  bwd: demb [vocab_rows, dim] is zeroed and
  * accumulated; row padding_idx receives nothing (nn.Embedding(padding_idx=PAD), :42-46). */
 int smt_lm_embed_fwd(const int64_t* tokens, const float* emb, const float* pe, float* out, int batch, int len, int dim,
-                     float mul, uint32_t drop_key, uint32_t drop_thresh16, float drop_scale, smt_stream_t stream);
+                     float mul, uint32_t drop_key, const uint32_t* drop_key_dev, uint32_t drop_thresh16, float drop_scale, smt_stream_t stream);
 int smt_lm_embed_bwd(const int64_t* tokens, const float* dout, float* demb, int batch, int len, int dim, int vocab_rows,
-                     float mul, uint32_t drop_key, uint32_t drop_thresh16, float drop_scale, int64_t padding_idx,
+                     float mul, uint32_t drop_key, const uint32_t* drop_key_dev, uint32_t drop_thresh16, float drop_scale, int64_t padding_idx,
                      smt_stream_t stream);
 
 /* Multi-head self-attention core of nn.MultiheadAttention as the reference calls it (:110-111,117: additive causal
@@ -341,10 +347,10 @@ int smt_lm_embed_bwd(const int64_t* tokens, const float* dout, float* demb, int 
  * (mask=None, :142); dropout index ((b*heads + h)*len + i)*len + j.
  * bwd writes dqkv [batch, len, 3*heads*32] (every element); delta [batch, heads, len] is scratch it fills and reads. */
 int smt_lm_attention_fwd(const float* qkv, const int* lens, float* ctx, float* lse, int batch, int len, int heads,
-                         int causal, uint32_t drop_key, uint32_t drop_thresh16, float drop_scale, smt_stream_t stream);
+                         int causal, uint32_t drop_key, const uint32_t* drop_key_dev, uint32_t drop_thresh16, float drop_scale, smt_stream_t stream);
 int smt_lm_attention_bwd(const float* qkv, const int* lens, const float* ctx, const float* lse, const float* dctx,
                          float* dqkv, float* delta, int batch, int len, int heads, int causal, uint32_t drop_key,
-                         uint32_t drop_thresh16, float drop_scale, smt_stream_t stream);
+                         const uint32_t* drop_key_dev, uint32_t drop_thresh16, float drop_scale, smt_stream_t stream);
 
 /* y = LayerNorm(x + dropout(h + h_bias)) * gamma + beta over the last dim (TransformerEncoderLayer, norm_first = False):
  * h is the bias-free output of out_proj / linear2 and h_bias [dim] that projection's bias (NULL = none), so that the
@@ -352,22 +358,22 @@ int smt_lm_attention_bwd(const float* qkv, const int* lens, const float* ctx, co
  * LayerNorm of the encoder (:63-66).  stats [rows, 2] = (mean, rstd).  dim = 64 * {1,2,4,8,12,16,32}.
  * bwd: dx / dh may be NULL (not wanted); dparams [3, dim] = dgamma, dbeta, dh_bias (column sums of dh). */
 int smt_lm_add_ln_fwd(const float* x, const float* h, const float* h_bias, const float* gamma, const float* beta, float* y,
-                      float* stats, int64_t rows, int dim, float eps, uint32_t drop_key, uint32_t drop_thresh16,
+                      float* stats, int64_t rows, int dim, float eps, uint32_t drop_key, const uint32_t* drop_key_dev, uint32_t drop_thresh16,
                       float drop_scale, smt_stream_t stream);
 size_t smt_lm_add_ln_bwd_workspace_bytes(int64_t rows, int dim);
 int smt_lm_add_ln_bwd(const float* x, const float* h, const float* h_bias, const float* dy, const float* gamma,
                       const float* stats, float* dx, float* dh, float* dparams, int64_t rows, int dim, uint32_t drop_key,
-                      uint32_t drop_thresh16, float drop_scale, void* workspace, size_t workspace_bytes,
-                      smt_stream_t stream);
+                      const uint32_t* drop_key_dev, uint32_t drop_thresh16, float drop_scale, void* workspace,
+                      size_t workspace_bytes, smt_stream_t stream);
 
 /* h <- dropout(relu(h + bias)) in place (linear1 -> activation -> dropout of the feed-forward).  bwd: dh = da * keep *
  * [a != 0] (a = the forward's result; dh may alias da), dbias [dim] = its column sums in a fixed order. */
-int smt_lm_bias_relu_fwd(float* h, const float* bias, int64_t rows, int dim, uint32_t drop_key, uint32_t drop_thresh16,
+int smt_lm_bias_relu_fwd(float* h, const float* bias, int64_t rows, int dim, uint32_t drop_key, const uint32_t* drop_key_dev, uint32_t drop_thresh16,
                          float drop_scale, smt_stream_t stream);
 size_t smt_lm_bias_relu_bwd_workspace_bytes(int64_t rows, int dim);
 int smt_lm_bias_relu_bwd(const float* a, const float* da, float* dh, float* dbias, int64_t rows, int dim, uint32_t drop_key,
-                         uint32_t drop_thresh16, float drop_scale, void* workspace, size_t workspace_bytes,
-                         smt_stream_t stream);
+                         const uint32_t* drop_key_dev, uint32_t drop_thresh16, float drop_scale, void* workspace,
+                         size_t workspace_bytes, smt_stream_t stream);
 
 /* Next-token cross entropy and accuracy (:121-128).  target [rows] int64, < 0 = row not counted (the reference's
  * loss_mask); row_out [rows, 2] = (logsumexp - logit[target] or 0, argmax == target as 0/1, lowest index on ties);

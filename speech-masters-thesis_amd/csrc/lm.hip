@@ -25,7 +25,8 @@ __device__ __forceinline__ float lm_keep(unsigned long long i, unsigned key, uns
 // ------------------------------------------------------------------------------------------------ embedding
 __global__ __launch_bounds__(256) void lm_embed_fwd_kernel(const long long* __restrict__ tok, const float* __restrict__ emb,
                                                            const float* __restrict__ pe, float* __restrict__ out, int B, int L,
-                                                           int D, float mul, unsigned key, unsigned thr, float dscale) {
+                                                           int D, float mul, unsigned key, const unsigned* __restrict__ key_dev, unsigned thr, float dscale) {
+  if (key_dev) key = *key_dev;                                // device-resident key (graph replay): overrides the by-value one
   const long long total = (long long)B * L * D;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
     const int c = (int)(e % D);
@@ -38,7 +39,8 @@ __global__ __launch_bounds__(256) void lm_embed_fwd_kernel(const long long* __re
 // dW[token] += dout * mask * mul (the padding row 0 gets no gradient: nn.Embedding(padding_idx = 0))
 __global__ __launch_bounds__(256) void lm_embed_bwd_kernel(const long long* __restrict__ tok, const float* __restrict__ dout,
                                                            float* __restrict__ demb, int B, int L, int D, float mul,
-                                                           unsigned key, unsigned thr, float dscale, long long pad_idx) {
+                                                           unsigned key, const unsigned* __restrict__ key_dev, unsigned thr, float dscale, long long pad_idx) {
+  if (key_dev) key = *key_dev;                                // device-resident key (graph replay): overrides the by-value one
   const long long total = (long long)B * L * D;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
     const long long t = tok[e / D];
@@ -142,7 +144,8 @@ constexpr float LM_LOG2E = 1.4426950408889634f;
 
 __global__ __launch_bounds__(256) void lm_attn_fwd_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
                                                           float* __restrict__ ctx, float* __restrict__ lse, int L, int H,
-                                                          int causal, unsigned key, unsigned thr, float dscale) {
+                                                          int causal, unsigned key, const unsigned* __restrict__ key_dev, unsigned thr, float dscale) {
+  if (key_dev) key = *key_dev;                                // device-resident key (graph replay): overrides the by-value one
   __shared__ float red[AT_W * 16 * 64];
   __shared__ float red_m[AT_W][64], red_z[AT_W][64];
   const int qb = gridDim.x - 1 - blockIdx.x;                  // longest (last) query blocks first
@@ -218,7 +221,8 @@ __global__ __launch_bounds__(256) void lm_attn_dq_kernel(const float* __restrict
                                                          const float* __restrict__ ctx, const float* __restrict__ lse,
                                                          const float* __restrict__ dctx, float* __restrict__ dqkv,
                                                          float* __restrict__ delta, int L, int H, int causal, unsigned key,
-                                                         unsigned thr, float dscale) {
+                                                         const unsigned* __restrict__ key_dev, unsigned thr, float dscale) {
+  if (key_dev) key = *key_dev;                                // device-resident key (graph replay): overrides the by-value one
   __shared__ float red[AT_W * 16 * 64];
   const int qb = gridDim.x - 1 - blockIdx.x;
   const int b = blockIdx.y / H, h = blockIdx.y % H, d = H * LM_DH;
@@ -276,7 +280,8 @@ __global__ __launch_bounds__(256) void lm_attn_dq_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void lm_attn_dkv_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
                                                           const float* __restrict__ lse, const float* __restrict__ dctx,
                                                           const float* __restrict__ delta, float* __restrict__ dqkv, int L,
-                                                          int H, int causal, unsigned key, unsigned thr, float dscale) {
+                                                          int H, int causal, unsigned key, const unsigned* __restrict__ key_dev, unsigned thr, float dscale) {
+  if (key_dev) key = *key_dev;                                // device-resident key (graph replay): overrides the by-value one
   __shared__ float red[AT_W * 16 * 64];
   const int kb = blockIdx.x;                                  // first key blocks see the most queries: longest first
   const int b = blockIdx.y / H, h = blockIdx.y % H, d = H * LM_DH;
@@ -328,7 +333,8 @@ __global__ __launch_bounds__(256) void lm_add_ln_fwd_kernel(const float* __restr
                                                             const float* __restrict__ hbias,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ y, float* __restrict__ stats, long long rows,
-                                                            float eps, unsigned key, unsigned thr, float dscale) {
+                                                            float eps, unsigned key, const unsigned* __restrict__ key_dev, unsigned thr, float dscale) {
+  if (key_dev) key = *key_dev;                                // device-resident key (graph replay): overrides the by-value one
   constexpr int C = PER * 64;
   const int lane = threadIdx.x & 63;
   const long long row = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
@@ -363,7 +369,8 @@ __global__ __launch_bounds__(256) void lm_add_ln_bwd_kernel(const float* __restr
                                                             const float* __restrict__ dy, const float* __restrict__ gamma,
                                                             const float* __restrict__ stats, float* __restrict__ dx,
                                                             float* __restrict__ dh, float* __restrict__ part, long long rows,
-                                                            unsigned key, unsigned thr, float dscale) {
+                                                            unsigned key, const unsigned* __restrict__ key_dev, unsigned thr, float dscale) {
+  if (key_dev) key = *key_dev;                                // device-resident key (graph replay): overrides the by-value one
   constexpr int C = PER * 64;
   extern __shared__ float red[];                              // [4][3][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -443,7 +450,8 @@ __global__ __launch_bounds__(256) void lm_colsum_kernel(const float* __restrict_
 
 // ------------------------------------------------------------------------------------------------ bias + relu + dropout
 __global__ __launch_bounds__(256) void lm_bias_relu_fwd_kernel(float* __restrict__ hbuf, const float* __restrict__ bias,
-                                                               long long rows, int C, unsigned key, unsigned thr, float dscale) {
+                                                               long long rows, int C, unsigned key, const unsigned* __restrict__ key_dev, unsigned thr, float dscale) {
+  if (key_dev) key = *key_dev;                                // device-resident key (graph replay): overrides the by-value one
   const long long total = rows * C;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
     const float v = fmaxf(hbuf[e] + bias[e % C], 0.f);
@@ -453,7 +461,8 @@ __global__ __launch_bounds__(256) void lm_bias_relu_fwd_kernel(float* __restrict
 // dh = da * mask * [a != 0] (dh may be da); bias-gradient partials per workgroup row block -> part [nblk][C]
 __global__ __launch_bounds__(256) void lm_bias_relu_bwd_kernel(const float* __restrict__ a, const float* da, float* dh,
                                                                float* __restrict__ part, long long rows, int C, int rows_per_blk,
-                                                               unsigned key, unsigned thr, float dscale) {
+                                                               unsigned key, const unsigned* __restrict__ key_dev, unsigned thr, float dscale) {
+  if (key_dev) key = *key_dev;                                // device-resident key (graph replay): overrides the by-value one
   const long long r0 = (long long)blockIdx.x * rows_per_blk;
   for (int c = blockIdx.y * 256 + threadIdx.x; c < C; c += 256 * gridDim.y) {
     float s = 0.f;
@@ -510,25 +519,40 @@ __global__ __launch_bounds__(256) void lm_ce_bwd_kernel(const float* __restrict_
   }
 }
 
+// keys[s] = fmix32(seed * 0x9E3779B1 + s * 0x7F4A7C15 + 1): the per-site dropout keys (smt_amd.convops.dropout_key) of the step
+// whose seed sits in device memory -- what a captured graph replays with a new seed every time
+__global__ void lm_make_keys_kernel(const unsigned* __restrict__ seed, unsigned* __restrict__ keys, int n) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s < n) keys[s] = fmix32(seed[0] * 0x9E3779B1u + (unsigned)s * 0x7F4A7C15u + 1u);
+}
+
 static unsigned lm_grid(long long total) { return (unsigned)std::min<long long>(4096, (total + 255) / 256); }
 
 }  // namespace smt
 
 using namespace smt;
 
+extern "C" int smt_lm_make_keys(const uint32_t* seed_dev, uint32_t* keys_dev, int n_sites, smt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SMT_CHECK_ARG(seed_dev && keys_dev && n_sites > 0, "smt_lm_make_keys: bad arguments");
+  lm_make_keys_kernel<<<(n_sites + 255) / 256, 256, 0, stream>>>(seed_dev, keys_dev, n_sites);
+  SMT_CHECK_LAUNCH("lm_make_keys");
+  return 0;
+}
+
 extern "C" int smt_lm_embed_fwd(const int64_t* tokens, const float* emb, const float* pe, float* out, int batch, int len, int dim,
-                                float mul, uint32_t drop_key, uint32_t drop_thresh16, float drop_scale, smt_stream_t stream_) {
+                                float mul, uint32_t drop_key, const uint32_t* drop_key_dev, uint32_t drop_thresh16, float drop_scale, smt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (batch <= 0 || len <= 0) return 0;
   SMT_CHECK_ARG(tokens && emb && pe && out, "smt_lm_embed_fwd: null pointer");
   lm_embed_fwd_kernel<<<lm_grid((long long)batch * len * dim), 256, 0, stream>>>((const long long*)tokens, emb, pe, out, batch, len, dim,
-                                                                             mul, drop_key, drop_thresh16, drop_scale);
+                                                                             mul, drop_key, drop_key_dev, drop_thresh16, drop_scale);
   SMT_CHECK_LAUNCH("lm_embed_fwd");
   return 0;
 }
 
 extern "C" int smt_lm_embed_bwd(const int64_t* tokens, const float* dout, float* demb, int batch, int len, int dim, int vocab_rows,
-                                float mul, uint32_t drop_key, uint32_t drop_thresh16, float drop_scale, int64_t padding_idx,
+                                float mul, uint32_t drop_key, const uint32_t* drop_key_dev, uint32_t drop_thresh16, float drop_scale, int64_t padding_idx,
                                 smt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SMT_CHECK_ARG(demb, "smt_lm_embed_bwd: null pointer");
@@ -536,19 +560,19 @@ extern "C" int smt_lm_embed_bwd(const int64_t* tokens, const float* dout, float*
   if (batch <= 0 || len <= 0) return 0;
   SMT_CHECK_ARG(tokens && dout, "smt_lm_embed_bwd: null pointer");
   lm_embed_bwd_kernel<<<lm_grid((long long)batch * len * dim), 256, 0, stream>>>((const long long*)tokens, dout, demb, batch, len, dim,
-                                                                             mul, drop_key, drop_thresh16, drop_scale, padding_idx);
+                                                                             mul, drop_key, drop_key_dev, drop_thresh16, drop_scale, padding_idx);
   SMT_CHECK_LAUNCH("lm_embed_bwd");
   return 0;
 }
 
 extern "C" int smt_lm_attention_fwd(const float* qkv, const int* lens, float* ctx, float* lse, int batch, int len, int heads,
-                                    int causal, uint32_t drop_key, uint32_t drop_thresh16, float drop_scale, smt_stream_t stream_) {
+                                    int causal, uint32_t drop_key, const uint32_t* drop_key_dev, uint32_t drop_thresh16, float drop_scale, smt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (batch <= 0 || len <= 0) return 0;
   SMT_CHECK_ARG(qkv && ctx && lse, "smt_lm_attention_fwd: null pointer");
   SMT_CHECK_ARG(len <= LM_MAXL && heads >= 1, "smt_lm_attention_fwd: len must be <= %d (got %d)", LM_MAXL, len);
   SMT_CHECK_ARG((long long)batch * heads <= 65535, "smt_lm_attention_fwd: batch * heads must be <= 65535");
-  lm_attn_fwd_kernel<<<dim3((len + 31) / 32, batch * heads), 256, 0, stream>>>(qkv, lens, ctx, lse, len, heads, causal, drop_key,
+  lm_attn_fwd_kernel<<<dim3((len + 31) / 32, batch * heads), 256, 0, stream>>>(qkv, lens, ctx, lse, len, heads, causal, drop_key, drop_key_dev,
                                                                            drop_thresh16, drop_scale);
   SMT_CHECK_LAUNCH("lm_attention_fwd");
   return 0;
@@ -556,17 +580,17 @@ extern "C" int smt_lm_attention_fwd(const float* qkv, const int* lens, float* ct
 
 extern "C" int smt_lm_attention_bwd(const float* qkv, const int* lens, const float* ctx, const float* lse, const float* dctx,
                                     float* dqkv, float* delta, int batch, int len, int heads, int causal, uint32_t drop_key,
-                                    uint32_t drop_thresh16, float drop_scale, smt_stream_t stream_) {
+                                    const uint32_t* drop_key_dev, uint32_t drop_thresh16, float drop_scale, smt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (batch <= 0 || len <= 0) return 0;
   SMT_CHECK_ARG(qkv && ctx && lse && dctx && dqkv && delta, "smt_lm_attention_bwd: null pointer");
   SMT_CHECK_ARG(len <= LM_MAXL && heads >= 1, "smt_lm_attention_bwd: len must be <= %d (got %d)", LM_MAXL, len);
   SMT_CHECK_ARG((long long)batch * heads <= 65535, "smt_lm_attention_bwd: batch * heads must be <= 65535");
   const dim3 grid((len + 31) / 32, batch * heads);
-  lm_attn_dq_kernel<<<grid, 256, 0, stream>>>(qkv, lens, ctx, lse, dctx, dqkv, delta, len, heads, causal, drop_key, drop_thresh16,
+  lm_attn_dq_kernel<<<grid, 256, 0, stream>>>(qkv, lens, ctx, lse, dctx, dqkv, delta, len, heads, causal, drop_key, drop_key_dev, drop_thresh16,
                                             drop_scale);
   SMT_CHECK_LAUNCH("lm_attention_dq");
-  lm_attn_dkv_kernel<<<grid, 256, 0, stream>>>(qkv, lens, lse, dctx, delta, dqkv, len, heads, causal, drop_key, drop_thresh16,
+  lm_attn_dkv_kernel<<<grid, 256, 0, stream>>>(qkv, lens, lse, dctx, delta, dqkv, len, heads, causal, drop_key, drop_key_dev, drop_thresh16,
                                              drop_scale);
   SMT_CHECK_LAUNCH("lm_attention_dkv");
   return 0;
@@ -574,14 +598,14 @@ extern "C" int smt_lm_attention_bwd(const float* qkv, const int* lens, const flo
 
 extern "C" int smt_lm_add_ln_fwd(const float* x, const float* h, const float* h_bias, const float* gamma, const float* beta, float* y,
                                  float* stats,
-                                 int64_t rows, int dim, float eps, uint32_t drop_key, uint32_t drop_thresh16, float drop_scale,
+                                 int64_t rows, int dim, float eps, uint32_t drop_key, const uint32_t* drop_key_dev, uint32_t drop_thresh16, float drop_scale,
                                  smt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (rows <= 0) return 0;
   SMT_CHECK_ARG((x || h) && gamma && beta && y && stats, "smt_lm_add_ln_fwd: null pointer");
   SMT_CHECK_ARG(dim % 64 == 0 && dim <= 2048, "smt_lm_add_ln_fwd: dim must be a multiple of 64 up to 2048 (got %d)", dim);
 #define LM_CALL(P) lm_add_ln_fwd_kernel<P><<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>(x, h, h_bias, gamma, beta, y, stats, rows, eps, \
-                                                                                     drop_key, drop_thresh16, drop_scale)
+                                                                                     drop_key, drop_key_dev, drop_thresh16, drop_scale)
   LM_LN_DISPATCH(dim, LM_CALL)
 #undef LM_CALL
   SMT_CHECK_LAUNCH("lm_add_ln_fwd");
@@ -594,7 +618,7 @@ extern "C" size_t smt_lm_add_ln_bwd_workspace_bytes(int64_t rows, int dim) {
 
 extern "C" int smt_lm_add_ln_bwd(const float* x, const float* h, const float* h_bias, const float* dy, const float* gamma,
                                  const float* stats, float* dx, float* dh, float* dparams, int64_t rows, int dim, uint32_t drop_key,
-                                 uint32_t drop_thresh16, float drop_scale, void* workspace, size_t workspace_bytes,
+                                 const uint32_t* drop_key_dev, uint32_t drop_thresh16, float drop_scale, void* workspace, size_t workspace_bytes,
                                  smt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SMT_CHECK_ARG(dparams, "smt_lm_add_ln_bwd: null pointer");
@@ -611,7 +635,7 @@ extern "C" int smt_lm_add_ln_bwd(const float* x, const float* h, const float* h_
 #define LM_CALL(P)                                                                                                        \
   (void)hipFuncSetAttribute((const void*)lm_add_ln_bwd_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
   lm_add_ln_bwd_kernel<P><<<nblk, 256, lds, stream>>>(x, h, h_bias, dy, gamma, stats, dx, dh, part, rows, drop_key,        \
-                                                      drop_thresh16, drop_scale)
+                                                      drop_key_dev, drop_thresh16, drop_scale)
   LM_LN_DISPATCH(dim, LM_CALL)
 #undef LM_CALL
   SMT_CHECK_LAUNCH("lm_add_ln_bwd");
@@ -620,12 +644,12 @@ extern "C" int smt_lm_add_ln_bwd(const float* x, const float* h, const float* h_
   return 0;
 }
 
-extern "C" int smt_lm_bias_relu_fwd(float* h, const float* bias, int64_t rows, int dim, uint32_t drop_key, uint32_t drop_thresh16,
+extern "C" int smt_lm_bias_relu_fwd(float* h, const float* bias, int64_t rows, int dim, uint32_t drop_key, const uint32_t* drop_key_dev, uint32_t drop_thresh16,
                                     float drop_scale, smt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (rows <= 0) return 0;
   SMT_CHECK_ARG(h && bias, "smt_lm_bias_relu_fwd: null pointer");
-  lm_bias_relu_fwd_kernel<<<lm_grid(rows * dim), 256, 0, stream>>>(h, bias, rows, dim, drop_key, drop_thresh16, drop_scale);
+  lm_bias_relu_fwd_kernel<<<lm_grid(rows * dim), 256, 0, stream>>>(h, bias, rows, dim, drop_key, drop_key_dev, drop_thresh16, drop_scale);
   SMT_CHECK_LAUNCH("lm_bias_relu_fwd");
   return 0;
 }
@@ -633,7 +657,7 @@ extern "C" int smt_lm_bias_relu_fwd(float* h, const float* bias, int64_t rows, i
 extern "C" size_t smt_lm_bias_relu_bwd_workspace_bytes(int64_t rows, int dim) { return (size_t)((rows + 15) / 16) * dim * sizeof(float); }
 
 extern "C" int smt_lm_bias_relu_bwd(const float* a, const float* da, float* dh, float* dbias, int64_t rows, int dim, uint32_t drop_key,
-                                    uint32_t drop_thresh16, float drop_scale, void* workspace, size_t workspace_bytes,
+                                    const uint32_t* drop_key_dev, uint32_t drop_thresh16, float drop_scale, void* workspace, size_t workspace_bytes,
                                     smt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SMT_CHECK_ARG(dbias, "smt_lm_bias_relu_bwd: null pointer");
@@ -641,7 +665,7 @@ extern "C" int smt_lm_bias_relu_bwd(const float* a, const float* da, float* dh, 
   SMT_CHECK_ARG(a && da && dh && workspace, "smt_lm_bias_relu_bwd: null pointer");
   SMT_CHECK_ARG(workspace_bytes >= smt_lm_bias_relu_bwd_workspace_bytes(rows, dim), "smt_lm_bias_relu_bwd: workspace too small");
   const int nblk = (int)((rows + 15) / 16);
-  lm_bias_relu_bwd_kernel<<<dim3(nblk, (dim + 255) / 256), 256, 0, stream>>>(a, da, dh, (float*)workspace, rows, dim, 16, drop_key, drop_thresh16, drop_scale);
+  lm_bias_relu_bwd_kernel<<<dim3(nblk, (dim + 255) / 256), 256, 0, stream>>>(a, da, dh, (float*)workspace, rows, dim, 16, drop_key, drop_key_dev, drop_thresh16, drop_scale);
   SMT_CHECK_LAUNCH("lm_bias_relu_bwd");
   lm_colsum_kernel<<<(dim + 63) / 64, 256, 0, stream>>>((const float*)workspace, dbias, nblk, dim);
   SMT_CHECK_LAUNCH("lm_colsum");

@@ -63,16 +63,16 @@ class _EncoderLayer(nn.Module):
         self.norm2 = nn.LayerNorm(d_model, eps=layer_norm_eps)
         self.p = dropout
 
-    def forward(self, x, lens, causal, seed, site0):
+    def forward(self, x, lens, causal, seed, site0, kd=None):
         sa, tr, p = self.self_attn, self.training, self.p
         qkv = F.linear(x, sa.in_proj_weight, sa.in_proj_bias)
-        ctx = K.attention(qkv, lens, sa.num_heads, causal, K.Drop(p, tr, seed, site0))
+        ctx = K.attention(qkv, lens, sa.num_heads, causal, K.Drop(p, tr, seed, site0, kd))
         a = F.linear(ctx, sa.out_proj.weight)                      # its bias is added (and differentiated) inside add_layer_norm
-        x = K.add_layer_norm(x, a, self.norm1.weight, self.norm1.bias, self.norm1.eps, K.Drop(p, tr, seed, site0 + 1),
+        x = K.add_layer_norm(x, a, self.norm1.weight, self.norm1.bias, self.norm1.eps, K.Drop(p, tr, seed, site0 + 1, kd),
                              h_bias=sa.out_proj.bias)
-        f = K.bias_relu_dropout_(F.linear(x, self.linear1.weight), self.linear1.bias, K.Drop(p, tr, seed, site0 + 2))
+        f = K.bias_relu_dropout_(F.linear(x, self.linear1.weight), self.linear1.bias, K.Drop(p, tr, seed, site0 + 2, kd))
         f = F.linear(f, self.linear2.weight)
-        return K.add_layer_norm(x, f, self.norm2.weight, self.norm2.bias, self.norm2.eps, K.Drop(p, tr, seed, site0 + 3),
+        return K.add_layer_norm(x, f, self.norm2.weight, self.norm2.bias, self.norm2.eps, K.Drop(p, tr, seed, site0 + 3, kd),
                                 h_bias=self.linear2.bias)
 
 
@@ -118,6 +118,19 @@ class TransformerLM(TokenToWaveformModel):
         else:
             raise ValueError(f"Loss function {m.loss_type} not supported")
         self._drop_seed = 0
+        self._seed_dev = self._keys_dev = None          # device-resident dropout keys (enable_device_keys)
+
+    def enable_device_keys(self, flag=True):
+        """Keep the dropout step counter and the per-site keys in device memory (smt_lm_make_keys) instead of passing keys
+        by value: a captured hipGraph of the train step then draws fresh masks on every replay (smt_amd/graph.py).  The
+        masks are the same either way -- the host counter `_drop_seed` and the device one advance together."""
+        if not flag:
+            self._seed_dev = self._keys_dev = None
+            return
+        dev = self.embedding.weight.device
+        self._seed_dev = torch.tensor([self._drop_seed & 0x7FFFFFFF], dtype=torch.int32, device=dev)
+        self._keys_dev = torch.zeros(1 + 4 * len(self.transformer.layers), dtype=torch.int32, device=dev)
+        K.make_keys(self._seed_dev, self._keys_dev)
 
     @staticmethod
     def load_vqvae(log_dir, ckpt_num):
@@ -147,11 +160,11 @@ class TransformerLM(TokenToWaveformModel):
 
     def logits(self, x, lens, causal=True):
         """tokens [B, L] int64 (+ int32 lengths or None) -> next-token logits [B, L, vocab]."""
-        seed, tr = self._drop_seed, self.training
-        h = K.embed(x, self.embedding.weight, self.pos_encoding.table(), K.Drop(self.pos_encoding.p, tr, seed, 0),
+        seed, tr, kd = self._drop_seed, self.training, self._keys_dev
+        h = K.embed(x, self.embedding.weight, self.pos_encoding.table(), K.Drop(self.pos_encoding.p, tr, seed, 0, kd),
                     TransformerLM.PAD)
         for i, layer in enumerate(self.transformer.layers):
-            h = layer(h, lens, causal, seed, 1 + 4 * i)
+            h = layer(h, lens, causal, seed, 1 + 4 * i, kd)
         norm = self.transformer.norm
         h = K.add_layer_norm(h, None, norm.weight, norm.bias, norm.eps)
         return F.linear(h, self.classifier.weight, self.classifier.bias)
@@ -161,6 +174,9 @@ class TransformerLM(TokenToWaveformModel):
         lens = x_lengths.to(device=x.device, dtype=torch.int32)
         if self.training:
             self._drop_seed += 1                                # one fresh set of dropout masks per training step
+            if self._keys_dev is not None:                      # the same counter on the device, and the keys derived from it
+                self._seed_dev.add_(1)
+                K.make_keys(self._seed_dev, self._keys_dev)
         xh = self.logits(x, lens, causal=True)
         # next-token targets (transformer_lm.py:121-126): position t predicts x[t + 1]; pads / specials are not scored
         nxt = x[:, 1:]

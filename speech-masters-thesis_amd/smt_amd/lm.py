@@ -16,14 +16,25 @@ from .convops import dropout_key
 
 
 class Drop:
-    """(key, thresh16, scale) of one dropout site; p = 0 or eval -> identity."""
-    __slots__ = ("key", "thresh", "scale")
+    """(key, thresh16, scale) of one dropout site; p = 0 or eval -> identity.  ``keys_dev`` (a device uint32/int32 tensor
+    of per-site keys written by ``make_keys``) makes the kernels read the key from device memory instead of taking it by
+    value: what a captured graph needs, since replays cannot change by-value arguments."""
+    __slots__ = ("key", "thresh", "scale", "key_dev")
 
-    def __init__(self, p=0.0, training=False, seed=0, site=0):
+    def __init__(self, p=0.0, training=False, seed=0, site=0, keys_dev=None):
+        self.key_dev = None
         if training and p > 0.0:
             self.key, self.thresh, self.scale = dropout_key(seed, site), int(round(p * 65536.0)), 1.0 / (1.0 - p)
+            if keys_dev is not None:
+                self.key_dev = keys_dev[site:site + 1]
         else:
             self.key, self.thresh, self.scale = 0, 0, 1.0
+
+
+def make_keys(seed_dev, keys_dev):
+    """keys_dev[s] = dropout_key(seed_dev[0], s) computed on the device (smt_lm_make_keys)."""
+    assert seed_dev.is_cuda and keys_dev.is_cuda and seed_dev.dtype == torch.int32 and keys_dev.dtype == torch.int32
+    N.check(N.lib().smt_lm_make_keys(N.ptr(seed_dev), N.ptr(keys_dev), keys_dev.numel(), N.stream_ptr()), "smt_lm_make_keys")
 
 
 NO_DROP = Drop()
@@ -41,7 +52,7 @@ class _Embed(torch.autograd.Function):
         d = weight.shape[1]
         tokens = tokens.contiguous()
         out = torch.empty(b, l, d, device=weight.device, dtype=torch.float32)
-        N.check(N.lib().smt_lm_embed_fwd(N.ptr(tokens), N.ptr(_f32(weight)), N.ptr(_f32(pe)), N.ptr(out), b, l, d, mul, drop.key,
+        N.check(N.lib().smt_lm_embed_fwd(N.ptr(tokens), N.ptr(_f32(weight)), N.ptr(_f32(pe)), N.ptr(out), b, l, d, mul, drop.key, N.ptr(drop.key_dev),
                                          drop.thresh, drop.scale, N.stream_ptr()), "smt_lm_embed_fwd")
         ctx.save_for_backward(tokens)
         ctx.meta = (weight.shape[0], d, mul, drop, padding_idx)
@@ -53,7 +64,7 @@ class _Embed(torch.autograd.Function):
         rows, d, mul, drop, padding_idx = ctx.meta
         b, l = tokens.shape
         demb = torch.empty(rows, d, device=dout.device, dtype=torch.float32)
-        N.check(N.lib().smt_lm_embed_bwd(N.ptr(tokens), N.ptr(_f32(dout)), N.ptr(demb), b, l, d, rows, mul, drop.key, drop.thresh,
+        N.check(N.lib().smt_lm_embed_bwd(N.ptr(tokens), N.ptr(_f32(dout)), N.ptr(demb), b, l, d, rows, mul, drop.key, N.ptr(drop.key_dev), drop.thresh,
                                          drop.scale, padding_idx, N.stream_ptr()), "smt_lm_embed_bwd")
         return None, demb, None, None, None, None
 
@@ -83,7 +94,7 @@ class _Attention(torch.autograd.Function):
         lse = torch.empty(b, heads, l, device=qkv.device, dtype=torch.float32)
         with profiler.region("lm_attention:fwd", flops=_attn_flops(b, heads, l, causal, 2), bound="mfma", dtype="f32"):
             N.check(N.lib().smt_lm_attention_fwd(N.ptr(qkv), N.ptr(lens), N.ptr(out), N.ptr(lse), b, l, heads, int(causal),
-                                                 drop.key, drop.thresh, drop.scale, N.stream_ptr()), "smt_lm_attention_fwd")
+                                                 drop.key, N.ptr(drop.key_dev), drop.thresh, drop.scale, N.stream_ptr()), "smt_lm_attention_fwd")
         ctx.save_for_backward(qkv, lens, out, lse)
         ctx.meta = (heads, int(causal), drop)
         return out
@@ -98,7 +109,7 @@ class _Attention(torch.autograd.Function):
         dout = _f32(dout)
         with profiler.region("lm_attention:bwd", flops=_attn_flops(b, heads, l, causal, 5), bound="mfma", dtype="f32"):
             N.check(N.lib().smt_lm_attention_bwd(N.ptr(qkv), N.ptr(lens), N.ptr(out), N.ptr(lse), N.ptr(dout), N.ptr(dqkv),
-                                                 N.ptr(delta), b, l, heads, causal, drop.key, drop.thresh, drop.scale,
+                                                 N.ptr(delta), b, l, heads, causal, drop.key, N.ptr(drop.key_dev), drop.thresh, drop.scale,
                                                  N.stream_ptr()), "smt_lm_attention_bwd")
         return dqkv, None, None, None, None
 
@@ -124,7 +135,7 @@ class _AddLayerNorm(torch.autograd.Function):
         n_in = (x is not None) + (h is not None)
         with profiler.region("lm_add_ln:fwd", nbytes=(n_in + 1) * rows * d * 4, bound="hbm"):
             N.check(N.lib().smt_lm_add_ln_fwd(N.ptr(x), N.ptr(h), N.ptr(h_bias), N.ptr(_f32(gamma)), N.ptr(_f32(beta)), N.ptr(y),
-                                              N.ptr(stats), rows, d, eps, drop.key, drop.thresh, drop.scale, N.stream_ptr()),
+                                              N.ptr(stats), rows, d, eps, drop.key, N.ptr(drop.key_dev), drop.thresh, drop.scale, N.stream_ptr()),
                     "smt_lm_add_ln_fwd")
         ctx.save_for_backward(x, h, h_bias, gamma, stats)
         ctx.meta = (rows, d, drop)
@@ -144,7 +155,7 @@ class _AddLayerNorm(torch.autograd.Function):
         n_io = 1 + (x is not None) + (h is not None) + (dx is not None) + (dh is not None)
         with profiler.region("lm_add_ln:bwd", nbytes=n_io * rows * d * 4, bound="hbm"):
             N.check(lib.smt_lm_add_ln_bwd(N.ptr(x), N.ptr(h), N.ptr(h_bias), N.ptr(dy), N.ptr(_f32(gamma)), N.ptr(stats), N.ptr(dx),
-                                          N.ptr(dh), N.ptr(dparams), rows, d, drop.key, drop.thresh, drop.scale, N.ptr(ws),
+                                          N.ptr(dh), N.ptr(dparams), rows, d, drop.key, N.ptr(drop.key_dev), drop.thresh, drop.scale, N.ptr(ws),
                                           ws_bytes, N.stream_ptr()), "smt_lm_add_ln_bwd")
         return dx, dh, (dparams[2] if h_bias is not None else None), dparams[0], dparams[1], None, None
 
@@ -163,7 +174,7 @@ class _BiasReluDrop(torch.autograd.Function):
         rows = h.numel() // d
         h = _f32(h)
         with profiler.region("lm_bias_relu:fwd", nbytes=2 * rows * d * 4, bound="hbm"):
-            N.check(N.lib().smt_lm_bias_relu_fwd(N.ptr(h), N.ptr(_f32(bias)), rows, d, drop.key, drop.thresh, drop.scale,
+            N.check(N.lib().smt_lm_bias_relu_fwd(N.ptr(h), N.ptr(_f32(bias)), rows, d, drop.key, N.ptr(drop.key_dev), drop.thresh, drop.scale,
                                                  N.stream_ptr()), "smt_lm_bias_relu_fwd")
         ctx.mark_dirty(h)
         ctx.save_for_backward(h)
@@ -181,7 +192,7 @@ class _BiasReluDrop(torch.autograd.Function):
         ws_bytes = lib.smt_lm_bias_relu_bwd_workspace_bytes(rows, d)
         ws = torch.empty(ws_bytes, device=a.device, dtype=torch.uint8)
         with profiler.region("lm_bias_relu:bwd", nbytes=3 * rows * d * 4, bound="hbm"):
-            N.check(lib.smt_lm_bias_relu_bwd(N.ptr(a), N.ptr(da), N.ptr(dh), N.ptr(dbias), rows, d, drop.key, drop.thresh, drop.scale,
+            N.check(lib.smt_lm_bias_relu_bwd(N.ptr(a), N.ptr(da), N.ptr(dh), N.ptr(dbias), rows, d, drop.key, N.ptr(drop.key_dev), drop.thresh, drop.scale,
                                              N.ptr(ws), ws_bytes, N.stream_ptr()), "smt_lm_bias_relu_bwd")
         return dh, dbias, None
 

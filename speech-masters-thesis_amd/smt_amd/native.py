@@ -73,20 +73,21 @@ _SIGNATURES = {
     "smt_stft_inverse": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "smt_conv_out_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr,
                                  c_size, c_ptr]),
-    "smt_lm_embed_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_f32, c_u32, c_u32, c_f32, c_ptr]),
-    "smt_lm_embed_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_f32, c_u32, c_u32, c_f32, c_i64,
+    "smt_lm_make_keys": (c_int, [c_ptr, c_ptr, c_int, c_ptr]),
+    "smt_lm_embed_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_f32, c_u32, c_ptr, c_u32, c_f32, c_ptr]),
+    "smt_lm_embed_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_f32, c_u32, c_ptr, c_u32, c_f32, c_i64,
                                  c_ptr]),
-    "smt_lm_attention_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_u32, c_u32, c_f32, c_ptr]),
-    "smt_lm_attention_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_u32, c_u32, c_f32,
+    "smt_lm_attention_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_u32, c_ptr, c_u32, c_f32, c_ptr]),
+    "smt_lm_attention_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_u32, c_ptr, c_u32, c_f32,
                                      c_ptr]),
-    "smt_lm_add_ln_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_u32, c_u32, c_f32,
+    "smt_lm_add_ln_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_u32, c_ptr, c_u32, c_f32,
                                   c_ptr]),
     "smt_lm_add_ln_bwd_workspace_bytes": (c_size, [c_i64, c_int]),
-    "smt_lm_add_ln_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_u32,
+    "smt_lm_add_ln_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_u32, c_ptr,
                                   c_u32, c_f32, c_ptr, c_size, c_ptr]),
-    "smt_lm_bias_relu_fwd": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_u32, c_u32, c_f32, c_ptr]),
+    "smt_lm_bias_relu_fwd": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_u32, c_ptr, c_u32, c_f32, c_ptr]),
     "smt_lm_bias_relu_bwd_workspace_bytes": (c_size, [c_i64, c_int]),
-    "smt_lm_bias_relu_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_u32, c_u32, c_f32, c_ptr, c_size, c_ptr]),
+    "smt_lm_bias_relu_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_u32, c_ptr, c_u32, c_f32, c_ptr, c_size, c_ptr]),
     "smt_lm_ce_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr]),
     "smt_lm_ce_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr]),
 }

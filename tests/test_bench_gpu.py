@@ -55,6 +55,8 @@ def test_transformer_lm_workload_line_and_two_rank_rehearsal():
     d2 = _run(["--gpus", "2"] + small, env={"SMT_BENCH_REHEARSAL": "1"})
     assert d2["n_gpus"] == 2 and d2["rehearsal_shared_gpu"] and d2["config"]["global_batch"] == 4
     assert abs(d2["value"] - 4 * 66 * 1000.0 / d2["ms_per_step"]) < 1e-6 * d2["value"]
+    d3 = _run(small + ["--lm_graph"])                       # forward + backward replayed as one captured hipGraph
+    assert d3["hip_graph"] and d3["value"] > 0 and d3["loss"] == d3["loss"]
 
 
 def test_aux_workload_reports_the_f_rows():

@@ -461,3 +461,58 @@ def test_full_size_attention_is_linear_in_the_values():
     assert torch.allclose(lhs, rhs, atol=2e-5) and float(lhs.abs().max()) > 0.1
     # scaling V by a power of two scales the context exactly
     assert torch.equal(att(4.0 * v1), 4.0 * att(v1))
+
+
+# ------------------------------------------------------------------------------------------------ device keys, graph
+def test_device_resident_keys_and_graphed_step_match_the_eager_step(tmp_path):
+    """Keys by value, keys from device memory and a hipGraph replay must draw the SAME masks step after step: three
+    training steps each way from the same weights and counter -> bit-identical losses; fresh masks on every replay."""
+    from smt_amd.graph import GraphedTrainStep
+    from utils.commons import get_optimizer
+    x, lens = lmo.synthetic_tokens(4, 60, 16, seed=8)
+    xd, ld = x.to(DEV), lens.to(DEV)
+    p32 = lmo.init_params(16, 64, 2, 128, 2, seed=81)
+
+    def fresh():
+        model, _ = _build(tmp_path, **dict(SMALL, dropout=0.1))
+        model.load_state_dict(p32, strict=False)
+        model.train()
+        model._drop_seed = 100
+        cfg = _lm_config(str(tmp_path / "vqvae"), **dict(SMALL, dropout=0.1))
+        opt, sched = get_optimizer(cfg, model)
+        return model, opt, sched
+
+    def eager(device_keys):
+        model, opt, sched = fresh()
+        if device_keys:
+            model.enable_device_keys(True)
+        out = []
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            loss = model(xd, ld, None, None)[0]["loss"]
+            loss.backward()
+            opt.step(); sched.step()
+            out.append(float(loss.detach()))
+        return out, model._drop_seed
+
+    by_value, seed_a = eager(False)
+    from_device, seed_b = eager(True)
+    assert by_value == from_device and seed_a == seed_b == 103
+    assert len(set(by_value)) == 3                                   # masks (and weights) change from step to step
+
+    model, opt, sched = fresh()
+    graphed = GraphedTrainStep(model, opt, sched, xd, ld, warmup=2)  # two warm-up forward/backward passes: counter 100 -> 102
+    assert model._drop_seed == 102 and int(model._seed_dev) == 102
+    # the graph continues from counter 102 with untouched weights: compare with an eager run brought to the same state
+    ref_model, ref_opt, ref_sched = fresh()
+    ref_model._drop_seed = 102
+    ref = []
+    for _ in range(3):
+        ref_opt.zero_grad(set_to_none=True)
+        loss = ref_model(xd, ld, None, None)[0]["loss"]
+        loss.backward()
+        ref_opt.step(); ref_sched.step()
+        ref.append(float(loss.detach()))
+    got = [float(graphed.step(xd, ld)) for _ in range(3)]
+    assert got == ref, (got, ref)
+    assert model._drop_seed == 105 and int(model._seed_dev) == 105

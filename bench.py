@@ -39,6 +39,9 @@ def parse(argv=None):
                         "pass, STFT.inverse, monotonic alignment search), each with its roofline and its CPU leg")
     p.add_argument("--lm_batch", type=int, default=8, help="sequences per GPU (scripts/train_transformer_lm.sh: 8)")
     p.add_argument("--lm_len", type=int, default=258, help="tokens per sequence (<bos> + 256 codes + pad)")
+    p.add_argument("--lm_tune_gemm", action="store_true",
+                   help="transformer_lm workload: let PyTorch's TunableOp pick the hipBLASLt / rocBLAS solution of every GEMM shape "
+                        "during warm-up (a few seconds; still plain library GEMMs)")
     p.add_argument("--lm_graph", action="store_true",
                    help="transformer_lm workload: replay forward + backward as one captured hipGraph (smt_amd/graph.py; single "
                         "GPU; no per-kernel events inside a graph)")
@@ -161,6 +164,12 @@ def lm_main(args, rank, world, device, rehearsal):
     from smt_amd import native, profiler
     from smt_amd.dist import GradSync
     native.lib()
+    if args.lm_tune_gemm:
+        import torch.cuda.tunable as tunable
+        tunable.enable(True)
+        tunable.tuning_enable(True)
+        tunable.set_max_tuning_duration(30)
+        tunable.set_filename(os.path.join(tempfile.gettempdir(), f"smt_lm_tunableop_{os.getpid()}.csv"))
     with tempfile.TemporaryDirectory() as tmp:
         model, optimizer, scheduler = bench_lm.build(tmp, "fp32", device)
     grad_sync = GradSync([p for p in model.parameters() if p.requires_grad], timing=True) if world > 1 else None
@@ -230,7 +239,7 @@ def lm_main(args, rank, world, device, rehearsal):
                 "value": args.lm_batch * args.lm_len * world * args.steps / elapsed, "unit": "tokens/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "rehearsal_shared_gpu": bool(rehearsal), "hip_graph": bool(args.lm_graph),
+                "rehearsal_shared_gpu": bool(rehearsal), "hip_graph": bool(args.lm_graph), "tuned_gemm": bool(args.lm_tune_gemm),
                 "config": {"workload": "models/transformer_lm (12 x d512, 16 heads, ff 2048, dropout 0.1, CE), "
                                        f"batch {args.lm_batch}/GPU x {args.lm_len} tokens, fp32, AdamW",
                            "global_batch": args.lm_batch * world, "seq_len": args.lm_len, "parallelism": f"dp{world}"},

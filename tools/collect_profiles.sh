@@ -27,6 +27,7 @@ python $R/bench.py --workload transformer_lm --steps 20 --warmup 5 > $O/lm_bench
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lm_stats -o lm -- python $R/bench.py --workload transformer_lm --steps 10 --warmup 3 --no_cpu_baseline --no_kernel_events > $O/lm_stats_bench.json 2> $O/lm_stats_bench.err
 rm -f $O/lm_stats/*kernel_trace.csv
 python $R/bench.py --workload transformer_lm --lm_graph --steps 30 --warmup 5 --no_cpu_baseline > $O/lm_bench_graph.json 2> $O/lm_bench_graph.err
+python $R/bench.py --workload transformer_lm --lm_graph --lm_tune_gemm --steps 30 --warmup 5 --no_cpu_baseline > $O/lm_bench_graph_tuned.json 2> $O/lm_bench_graph_tuned.err
 echo "[7/7] auxiliary paths (encode-only pass, STFT.inverse, maximum_path)"; date
 python $R/bench.py --workload aux --steps 10 --warmup 3 > $O/aux_bench.json 2> $O/aux_bench.err
 ls $O $O/stats $O/lm_stats

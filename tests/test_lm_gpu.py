@@ -466,7 +466,8 @@ def test_full_size_attention_is_linear_in_the_values():
 # ------------------------------------------------------------------------------------------------ device keys, graph
 def test_device_resident_keys_and_graphed_step_match_the_eager_step(tmp_path):
     """Keys by value, keys from device memory and a hipGraph replay must draw the SAME masks step after step: three
-    training steps each way from the same weights and counter -> bit-identical losses; fresh masks on every replay."""
+    training steps each way from the same weights and counter -> the same losses (bit-identical on the first step, to an
+    ulp-sized drift afterwards); fresh masks on every replay."""
     from smt_amd.graph import GraphedTrainStep
     from utils.commons import get_optimizer
     x, lens = lmo.synthetic_tokens(4, 60, 16, seed=8)
@@ -495,9 +496,14 @@ def test_device_resident_keys_and_graphed_step_match_the_eager_step(tmp_path):
             out.append(float(loss.detach()))
         return out, model._drop_seed
 
+    def same(a, b):
+        # step 1 starts from identical weights: identical masks -> bit-identical loss.  Later steps inherit the embedding
+        # gradient's f32 atomics (token collisions add in arrival order), which move the weights by an ulp from run to run
+        return a[0] == b[0] and all(abs(u - v) <= 2e-6 * abs(v) for u, v in zip(a, b))
+
     by_value, seed_a = eager(False)
     from_device, seed_b = eager(True)
-    assert by_value == from_device and seed_a == seed_b == 103
+    assert same(by_value, from_device) and seed_a == seed_b == 103
     assert len(set(by_value)) == 3                                   # masks (and weights) change from step to step
 
     model, opt, sched = fresh()
@@ -514,5 +520,5 @@ def test_device_resident_keys_and_graphed_step_match_the_eager_step(tmp_path):
         ref_opt.step(); ref_sched.step()
         ref.append(float(loss.detach()))
     got = [float(graphed.step(xd, ld)) for _ in range(3)]
-    assert got == ref, (got, ref)
+    assert same(got, ref), (got, ref)
     assert model._drop_seed == 105 and int(model._seed_dev) == 105

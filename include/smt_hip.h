@@ -186,6 +186,11 @@ typedef struct smt_conv_desc {
   const int* lens_in2;             /* rows >= lens_in2[b] of x2 read as 0 (lens_in applies to x only), or NULL */
   int c_in2, ld_x2;
   int64_t bs_x2;
+  /* Dropout keys in DEVICE memory (or NULL): site s uses drop_keys_dev[s * drop_keys_dev_stride] instead of drop_keys[s].
+   * A captured hipGraph freezes by-value arguments; a graphed train step keeps a table of per-site keys on the device and
+   * refreshes it with smt_lm_make_keys (the same derivation as the host's) before the first convolution of every step. */
+  const uint32_t* drop_keys_dev;
+  int drop_keys_dev_stride;
 } smt_conv_desc;
 int smt_conv1d_ntc(const smt_conv_desc* desc, smt_stream_t stream);
 /* Name of the kernel smt_conv1d_ntc dispatches this descriptor to ("conv_gemm", "conv_gemm_dma", "conv_ws",

@@ -35,11 +35,17 @@ struct ConvArgs {
   int out_stride, out_offset, Ty;       // output row = t*out_stride + out_offset, Ty rows in y per batch
   int act_out, epi_act;                 // relu+dropout of the OUTPUT (second store) / its derivative as epilogue
   unsigned drop_keys[8]; int site_width; unsigned drop_thresh16; float drop_scale;
+  const unsigned* drop_keys_dev; int drop_keys_dev_stride;   // keys in device memory (graph replay): override drop_keys
   int tiles_per_batch;
   int rs;   // row stride of the dilation-class decomposition (LDS-DMA kernel), 1 = off
   const void* x2; const void* w2; const float* bias2; const int* lens_in2; long long x2_bs; int ldx2;   // folded second 1x1 term (conv1x1_fold)
   int dbg;  // ablation switches (SMT_CONV_DBG): 1 no A loads, 2 no W loads, 4 no MFMA, 8 no stores
 };
+
+// dropout key of site s of this launch: by value, or from device memory when the caller keeps its keys there
+__device__ __forceinline__ unsigned site_key(const ConvArgs& p, int site) {
+  return p.drop_keys_dev ? p.drop_keys_dev[(site & 7) * p.drop_keys_dev_stride] : p.drop_keys[site & 7];
+}
 
 template <typename T>
 __device__ __forceinline__ void mma_step(const T* a, const T* b, f32x16& acc);
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(ConvArgs p) {
     if (p.epi_act && okv[it]) uv[it] = *reinterpret_cast<const Vec<T, EPV>*>(hg + (long long)ty * p.ldgh + col);
   }
   const int site = p.act_out ? col / p.site_width : 0;
-  const unsigned key = p.drop_keys[site & 7];
+  const unsigned key = site_key(p, site);
   const int cs = col - site * (p.act_out ? p.site_width : 0);
 #pragma unroll
   for (int it = 0; it < NE; ++it) {
@@ -454,7 +460,7 @@ __global__ __launch_bounds__(DMA_NT) void conv_gemm_dma_kernel(ConvArgs p, const
   T* yg = p.y ? reinterpret_cast<T*>(p.y) + (long long)b * p.y_bs : nullptr;
   const int len_out = p.lens_out ? p.lens_out[b] : 0x7fffffff;
   const int site = p.act_out ? col / p.site_width : 0;
-  const unsigned key = p.drop_keys[site & 7];
+  const unsigned key = site_key(p, site);
   const int cs = col - site * (p.act_out ? p.site_width : 0);
 #pragma unroll
   for (int it = 0; it < NE; ++it) {
@@ -537,7 +543,7 @@ __global__ __launch_bounds__(DMA_NT) void conv1x1_dma_kernel(ConvArgs p, const _
   const int cv0 = tid % CV, row0 = tid / CV;
   const int col = n0 + cv0 * EPV;
   const int site = p.act_out ? col / p.site_width : 0;
-  const unsigned key = p.drop_keys[site & 7];
+  const unsigned key = site_key(p, site);
   const int cs = col - site * (p.act_out ? p.site_width : 0);
 
   auto stage_a = [&](int tile, int buf) {
@@ -876,7 +882,7 @@ __global__ __launch_bounds__(WS_NT) void conv_ws_kernel(ConvArgs p, const __bf16
         if (has_act_out) {
           const int col = col0 + 8 * g;
           const int site = col / p.site_width;
-          const unsigned key = p.drop_keys[site & 7];
+          const unsigned key = site_key(p, site);
           const unsigned long long base = ((unsigned long long)b * p.Ty + ty) * p.site_width + (col - site * p.site_width);
 #pragma unroll
           for (int k = 0; k < 4; k += 2) {
@@ -983,7 +989,7 @@ __global__ __launch_bounds__(WS_NT) void conv_ws_pipe_kernel(ConvArgs p, const _
   for (int g = 0; g < 4; ++g) {
     const int col = col0 + 8 * g;
     const int site = col / p.site_width;
-    keyg[g] = p.drop_keys[site & 7];
+    keyg[g] = site_key(p, site);
     cshalf[g] = (unsigned)(col - site * p.site_width) >> 1;
   }
   const int rows_in = BM + (NTAPS - 1) * p.dil;
@@ -1358,7 +1364,7 @@ __global__ __launch_bounds__(K1_NT) void conv_k1act_kernel(ConvArgs p, const __b
 #pragma unroll
     for (int e = 0; e < 16; ++e) bval[c][e] = p.bias ? p.bias[col0 + 8 * (e >> 2) + (e & 3)] : 0.f;
     const int site = col0 / p.site_width;            // a 32-channel tile never straddles a site (site_width % 32 == 0)
-    keys[c] = p.drop_keys[site & 7];
+    keys[c] = site_key(p, site);
     cs[c] = col0 - site * p.site_width;
   }
 
@@ -1686,6 +1692,7 @@ static void conv_args_from_desc(const smt_conv_desc* d, ConvArgs& p) {
   p.y_act = d->y_act; p.ya_bs = d->bs_yact; p.ldya = d->ld_yact;
   p.act_out = d->act_out; p.epi_act = d->act_grad;
   for (int i = 0; i < 8; ++i) p.drop_keys[i] = d->drop_keys[i];
+  p.drop_keys_dev = d->drop_keys_dev; p.drop_keys_dev_stride = d->drop_keys_dev_stride;
   p.site_width = d->site_width; p.drop_thresh16 = d->drop_thresh16; p.drop_scale = d->drop_scale;
   p.tiles_per_batch = 0;
   p.rs = 1;

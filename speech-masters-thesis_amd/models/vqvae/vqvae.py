@@ -57,6 +57,21 @@ class VQVAE(WaveformReconstructionModel):
         for stage in encoder.level_blocks:
             stage.act_dtype = self.compute_dtype
         self._drop_seed = 0
+        self._seed_dev = self._keys_dev = None     # device-resident dropout keys (enable_device_keys)
+        self._n_sites = encoder.n_sites + decoder.n_sites
+
+    def enable_device_keys(self, flag=True):
+        """Keep the dropout step counter and the per-site keys in device memory, refreshed at the top of every training
+        forward (smt_lm_make_keys), instead of passing keys by value: a captured hipGraph of the step then draws fresh
+        masks on every replay (smt_amd/graph.py).  Same masks either way: host and device counters advance together."""
+        if not flag:
+            self._seed_dev = self._keys_dev = None
+            return
+        dev = next(self.parameters()).device
+        self._seed_dev = torch.tensor([self._drop_seed & 0x7FFFFFFF], dtype=torch.int32, device=dev)
+        self._keys_dev = torch.zeros(max(8, self._n_sites + 8), dtype=torch.int32, device=dev)
+        from smt_amd import convops
+        convops.make_device_keys(self._seed_dev, self._keys_dev)
 
     # Checkpoints written by the reference carry the six DFT-basis buffers of the loss
     # (multi_stft_loss.stfts.N.{forward,inverse}_basis); they are derived data here.
@@ -70,10 +85,18 @@ class VQVAE(WaveformReconstructionModel):
         assert c == 1
         lens = x_lengths.to(torch.int32)
         self._drop_seed += 1
+        from smt_amd import convops
+        if self._keys_dev is not None:                 # the same counter on the device, and this step's keys derived from it
+            self._seed_dev.add_(1)
+            convops.make_device_keys(self._seed_dev, self._keys_dev)
         target = x.reshape(b, t)
-        z, z_lens = self.encoders[0](target, lens, self._drop_seed)
-        _, xqs, commits, vq_metrics = self.bottleneck([z.float()], [z_lens], **vq_kwargs)
-        y, _ = self.decoders[0](xqs[0].to(self.compute_dtype), z_lens, self._drop_seed)
+        previous, convops.DEVICE_KEYS = convops.DEVICE_KEYS, (self._keys_dev if self.training else None)
+        try:
+            z, z_lens = self.encoders[0](target, lens, self._drop_seed)
+            _, xqs, commits, vq_metrics = self.bottleneck([z.float()], [z_lens], **vq_kwargs)
+            y, _ = self.decoders[0](xqs[0].to(self.compute_dtype), z_lens, self._drop_seed)
+        finally:
+            convops.DEVICE_KEYS = previous
         assert y.shape == (b, t), f"Expected shape {(b, t)}, got {tuple(y.shape)}."
         loss_recon = self.multi_recon_loss(target, y, lens)
         loss_stft = self.multi_stft_loss(target, y, lens)

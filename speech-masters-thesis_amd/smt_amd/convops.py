@@ -41,7 +41,7 @@ class ConvDesc(ctypes.Structure):
                 ("w_swizzled", ctypes.c_int), ("zero_page", ctypes.c_void_p),
                 ("x2", ctypes.c_void_p), ("w2", ctypes.c_void_p), ("bias2", ctypes.c_void_p),
                 ("lens_in2", ctypes.c_void_p), ("c_in2", ctypes.c_int), ("ld_x2", ctypes.c_int),
-                ("bs_x2", ctypes.c_int64)]
+                ("bs_x2", ctypes.c_int64), ("drop_keys_dev", ctypes.c_void_p), ("drop_keys_dev_stride", ctypes.c_int)]
 
 
 @dataclass
@@ -405,12 +405,28 @@ def _conv_k1_bwd(dh, x, w_packed_bwd, res, dx, lens32, dweight, dbias):
                 "smt_conv_k1_bwd")
 
 
-def _set_act_out(d, u, keys, thresh, scale, site_width):
+# Per-site dropout keys in device memory (int32 tensor indexed by site id), set by a model around its forward when its step
+# is to be captured in a hipGraph (models/vqvae/vqvae.py::enable_device_keys); None = keys travel by value.
+DEVICE_KEYS = None
+
+
+def make_device_keys(seed_dev, keys_dev):
+    """keys_dev[s] = dropout_key(seed_dev[0], s) for every site s, on the device (smt_lm_make_keys: the derivation is the
+    same for every model of this build)."""
+    assert seed_dev.is_cuda and keys_dev.is_cuda and seed_dev.dtype == torch.int32 and keys_dev.dtype == torch.int32
+    N.check(N.lib().smt_lm_make_keys(_p(seed_dev), _p(keys_dev), keys_dev.numel(), N.stream_ptr()), "smt_lm_make_keys")
+
+
+def _set_act_out(d, u, keys, thresh, scale, site_width, first_site=None, site_stride=1):
     d.act_out, d.site_width = 1, site_width
     d.y_act, d.bs_yact, d.ld_yact = _geom(u)
     for i, k in enumerate(keys):
         d.drop_keys[i] = k
     d.drop_thresh16, d.drop_scale = thresh, scale
+    if DEVICE_KEYS is not None and thresh > 0 and first_site is not None:
+        assert first_site + (len(keys) - 1) * site_stride < DEVICE_KEYS.numel()
+        d.drop_keys_dev = ctypes.c_void_p(DEVICE_KEYS.data_ptr() + 4 * first_site)
+        d.drop_keys_dev_stride = site_stride
 
 
 def _set_act_grad(d, u, scale):
@@ -732,7 +748,7 @@ class _GatedHiFi(torch.autograd.Function):
         h1 = None if fold else torch.empty_like(u1)
         d1 = _base_desc(x, h1, lens32, w, depth * c2, 1, 1, 1, 0, t, t_y=t)
         d1.w, d1.bias = _p(_pack_cat_fwd([p[0] for p in br], dt)), _p(b1cat)
-        _set_act_out(d1, u1, [specs[d][0][0] for d in range(depth)], thresh, scale, c2)
+        _set_act_out(d1, u1, [specs[d][0][0] for d in range(depth)], thresh, scale, c2, site_base, 2)
         if fold:
             d1.zero_page = _p(_zero_page(dev))     # enables the persistent activated-output kernel (conv_k1act)
         _launch(d1, "conv_fwd", _conv_flops(d1), _conv_bytes(d1, x.element_size()))
@@ -748,7 +764,7 @@ class _GatedHiFi(torch.autograd.Function):
             d2.w, d2.bias = _p(wp2), _p(br[d][3])
             if dma:
                 _use_dma(d2, wp2)
-            _set_act_out(d2, u2_d, [specs[d][1][0]], thresh, scale, c2)
+            _set_act_out(d2, u2_d, [specs[d][1][0]], thresh, scale, c2, site_base + 2 * d + 1, 1)
             _launch(d2, "conv_fwd", _conv_flops(d2), _conv_bytes(d2, x.element_size()))
         k3gate = fold and depth == 4 and _K3GATE
         g = torch.empty(b, t, w, dtype=dt, device=dev)

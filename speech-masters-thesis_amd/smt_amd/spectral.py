@@ -14,6 +14,18 @@ from . import profiler
 _tables = {}
 
 
+_consts = {}
+
+
+def _const(values, device):
+    """A small fp32 constant on the device, uploaded once per (values, device): a fresh torch.tensor(..., device=cuda) in
+    every backward is a pageable host-to-device copy -- a launch more, and not capturable in a hipGraph."""
+    key = (tuple(float(v) for v in values), str(device))
+    if key not in _consts:
+        _consts[key] = torch.tensor(key[0], dtype=torch.float32, device=device)
+    return _consts[key]
+
+
 def _get_tables(n_fft, win_length, device):
     key = (n_fft, win_length, str(device))
     if key not in _tables:
@@ -107,7 +119,7 @@ class _StftLoss(torch.autograd.Function):
         window, tw = _get_tables(n_fft, win_length, y.device)
         coef = (g / (2.0 * b)) / root.clamp(min=1e-30)          # d sqrt(S)/dS = 1/(2 sqrt(S)), mean over B
         if not use_log:
-            coef = coef * torch.tensor([1.0, 0.0], device=coef.device)
+            coef = coef * _const([1.0, 0.0], coef.device)
         coef = coef.contiguous().float()
         dyh = torch.zeros_like(yh)
         with profiler.region("stft_loss_bwd", nbytes=3 * y.numel() * 4, bound="hbm"):
@@ -147,7 +159,7 @@ class _ReconLoss(torch.autograd.Function):
         l1, l2, linf, topk, has_lens = ctx.cfg
         lens32 = lens32 if has_lens else None
         b, t = y.shape
-        scale = torch.tensor([l1 / (b * t), 2.0 * l2 / (b * t), 2.0 * linf / b], dtype=torch.float32, device=y.device)
+        scale = _const([l1 / (b * t), 2.0 * l2 / (b * t), 2.0 * linf / b], y.device)
         coef = (g.reshape(1).float() * scale).contiguous()
         dyh = torch.empty_like(yh)
         with profiler.region("recon_loss_bwd", nbytes=3 * y.numel() * 4, bound="hbm"):

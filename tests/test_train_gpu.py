@@ -112,3 +112,71 @@ def test_resume_keeps_the_trained_codebook(tmp_path):
     trainlib.load_checkpoint(str(tmp_path / "ckpts" / "ckpt.ref.pt"), m3, o3, s3, e3, dev)
     b3 = m3.bottleneck.level_blocks[0]
     assert b3.init and torch.equal(b3.k, k_trained) and torch.equal(b3.k_sum, k_trained) and bool((b3.k_elem == 1).all())
+
+
+def test_device_keys_and_graphed_step_reproduce_the_eager_vqvae_step(tmp_path):
+    """dropout keys from device memory + forward/backward in a hipGraph, on a small bf16 VQ-VAE (dropout
+    on, ragged).  The checks are the ones that are deterministic (gradients carry f32-atomic noise from the spectral loss's
+    overlap-add, which Adam's first steps amplify, so multi-step loss curves of two runs of ANY mode drift apart):
+    (1) from equal weights the first loss is bit-identical with keys by value, keys from the device, and a graph replay;
+    (2) a second pass over the same weights draws NEW masks, the same ones eagerly and in the graph;
+    (3) after an optimizer step the replay matches an eager forward of the same model at the same counter -- the graph sees
+        the updated weights (the packed copies are refreshed inside it)."""
+    from oracle import vqvae_oracle as orc
+    from smt_amd.graph import GraphedStep
+    from utils import config as C
+    from utils.commons import get_model, get_optimizer
+    cfg = C.merge(C.load(os.path.join(PKG, "configs/models/vqvae.yaml")),
+                  C.load(os.path.join(PKG, "configs/datasets/synthetic_ljspeech.yaml")),
+                  C.create({"train": {"batch_size": 2, "n_gpus": 1, "ema": False, "grad_clip_norm": None, "seed": 0,
+                                      "log_dir": str(tmp_path), "total_epochs": 1}}))
+    cfg.model.update(C.create(dict(width=64, emb_width=128, l_bins=64, multipliers=[1, 1, 1], compute_dtype="bf16")))
+    cfg.model.loss.linf_topk = 128
+    cfg.model.revival_threshold = 0.0     # no code counts as dead: revival rows come from torch's generator, whose stream of
+    dev = torch.device("cuda", 0)         # draws a captured graph does not share with the eager runs it is compared with
+    x = orc.synthetic_clip_batch(2, 16384, 5).cuda()
+    lens = torch.tensor([16384, 12288]).cuda()
+    batch = [None, None, None, None, x, lens, None]
+
+    def fresh():
+        torch.manual_seed(0)
+        model, _ = get_model(C.create(cfg.to_dict()), dev)
+        opt, sched = get_optimizer(cfg, model)
+        model.train()
+        first, _ = model.supervised_step(batch)   # the first forward initialises the codebook from the batch (host-side branch)
+        first["loss"].backward()                  # ... and the first backward creates the packed data-gradient weights
+        opt.zero_grad(set_to_none=True)
+        model._drop_seed = 50
+        return model, opt, sched
+
+    def loss_of(model):
+        return float(model.supervised_step(batch)[0]["loss"].detach())
+
+    by_value = loss_of(fresh()[0])
+    m_dev, o_dev, _ = fresh()
+    m_dev.enable_device_keys(True)
+    m_gr, o_gr, _ = fresh()
+    graph = GraphedStep(m_gr, lambda *slots: m_gr.supervised_step(list(slots)), batch, lambda: o_gr.zero_grad(set_to_none=True),
+                        warmup=0)
+
+    def replay():
+        return float(graph.replay(*batch)[0]["loss"])
+
+    # (1)
+    o_dev.zero_grad(set_to_none=True)
+    out, _ = m_dev.supervised_step(batch)
+    out["loss"].backward()
+    first_dev, first_graph = float(out["loss"].detach()), replay()
+    assert by_value == first_dev == first_graph
+    assert m_dev._drop_seed == m_gr._drop_seed == int(m_dev._seed_dev) == int(m_gr._seed_dev) == 51
+    # (2)
+    second_dev, second_graph = loss_of(m_dev), replay()
+    assert second_dev == second_graph and second_dev != first_dev and int(m_gr._seed_dev) == 52
+    # (3)
+    o_gr.step()
+    third_graph = replay()
+    m_gr._drop_seed -= 1
+    m_gr._seed_dev.sub_(1)                       # rewind the counter: the same masks once more, eagerly
+    again = loss_of(m_gr)                        # (the codebook EMA has moved on by one forward: equal to ~1e-3, not bit for bit)
+    assert abs(again - third_graph) <= 1e-3 * abs(third_graph), (again, third_graph)
+    assert abs(third_graph - second_graph) >= 5 * abs(again - third_graph)      # stale packed weights would replay step 2's loss

@@ -60,6 +60,8 @@ def parse(argv=None):
     p.add_argument("--cpu_clip_len", type=int, default=CLIP_LEN // 2,
                    help="clip length of the bounded CPU-baseline sample (half an utterance keeps 3 + 5 steps near 20-30 s)")
     p.add_argument("--no_fp32", action="store_true", help="skip the secondary fp32 (parity path) measurement")
+    p.add_argument("--no_graph", action="store_true", help="skip the secondary hipGraph-replay measurement")
+    p.add_argument("--graph_leg", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("--fp32_steps", type=int, default=3)
     return p.parse_args(argv)
 
@@ -357,6 +359,70 @@ def launch_or_none(args, argv):
     return launcher.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + list(argv))
 
 
+def graph_leg_main(args, device):
+    """Child process of `timed_graph`: the SAME train step with forward + backward replayed from one captured hipGraph
+    (smt_amd/graph.py; dropout keys in device memory, packed weights refreshed inside the graph); NaN guard, AdamW, scheduler
+    and the parameter-EMA hook stay eager, exactly as in train.train_step.  Prints one small JSON object."""
+    from smt_amd import native
+    native.lib()
+    from smt_amd.graph import GraphedStep
+    from utils.commons import get_model, get_optimizer
+    from utils.train_utils import seed_all_rng
+    import train as trainlib
+    cfg = make_config(args)
+    seed_all_rng(cfg.train.seed)
+    model, ema = get_model(cfg, device, 0)
+    optimizer, scheduler = get_optimizer(cfg, model)
+    model.train()
+    pool = synthetic_batches(min(4, args.steps + args.warmup), args.batch, args.clip_len, 0, device)
+    for i in range(2):      # eager steps first: codebook initialisation and every lazily built buffer
+        trainlib.train_step(global_step=i, batch=pool[i % len(pool)], config=cfg, model=model, ema=ema, optimizer=optimizer,
+                            scheduler=scheduler, device=device, rank=0, grad_sync=None)
+    graph = GraphedStep(model, lambda *slots: model.supervised_step(list(slots)), pool[0],
+                        lambda: optimizer.zero_grad(set_to_none=True), warmup=1)
+
+    def step(i):
+        loss_dict, _ = graph.replay(*pool[i % len(pool)])
+        if torch.isnan(loss_dict["loss"]):
+            raise RuntimeError("Nan detected in loss")
+        optimizer.step()
+        scheduler.step()
+        ema.step()
+        return loss_dict
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss_dict = step(args.warmup + i)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    print(json.dumps({"value": args.batch * args.steps / el, "unit": "utterances/s", "ms_per_step": el / args.steps * 1e3,
+                      "steps": args.steps, "warmup": args.warmup, "loss": float(loss_dict["loss"]),
+                      "note": "same step in a fresh process, forward + backward as one captured hipGraph; optimizer / scheduler / "
+                              "NaN guard / EMA hook eager"}), flush=True)
+
+
+def timed_graph(args, note):
+    """Secondary measurement, in a CHILD process (a crash inside graph capture must not take the headline line with it)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--graph_leg", "--steps", str(args.steps), "--warmup", "2", "--batch",
+           str(args.batch), "--model", args.model, "--clip_len", str(args.clip_len)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            note(f"hipGraph leg failed (exit code {r.returncode})")
+            return {"error": f"exit code {r.returncode}: " + r.stderr[-300:]}
+        out = json.loads(lines[-1])
+        note(f"hipGraph replay: {out['ms_per_step']:.1f} ms/step")
+        return out
+    except Exception as e:
+        note(f"hipGraph leg failed: {e}")
+        return {"error": str(e)[:300]}
+
+
 def timed_fp32(args, pool, device, note):
     """Secondary measurement: the fp32 parity path (same model, same batch, compute_dtype fp32) for a few steps."""
     from utils.commons import get_model, get_optimizer
@@ -406,6 +472,8 @@ def main(argv=None):
     if world > 1:
         dist.init_process_group(backend="gloo" if rehearsal else "nccl", init_method="env://")
 
+    if args.graph_leg:
+        return graph_leg_main(args, device)
     if args.workload == "transformer_lm":
         return lm_main(args, rank, world, device, rehearsal)
     if args.workload == "aux":
@@ -586,6 +654,8 @@ def main(argv=None):
             "kernels": kernels,
         }
         note(f"timed region done: {line['value']:.2f} utt/s, {line['ms_per_step']:.1f} ms/step")
+        if world == 1 and not args.no_graph:
+            line["hip_graph"] = timed_graph(args, note)
         if world == 1 and not args.no_fp32 and m.get("compute_dtype") == "bf16":
             del model, optimizer, scheduler, ema
             torch.cuda.empty_cache()

@@ -21,10 +21,16 @@ class GraphedStep:
 
     ``replay(*inputs)`` copies the inputs into the static buffers, replays, and returns the (static) result tensors; the
     parameters' ``.grad`` tensors are static too, so an eager optimizer can read them afterwards.  Results are those of the
-    eager step: same kernels, same masks (the host counter ``model._drop_seed`` is advanced alongside the device one)."""
+    eager step: same kernels, same masks (the host counter ``model._drop_seed`` is advanced alongside the device one).
+
+    The caller must not keep a loss (or any tensor with a grad_fn) of an EARLIER eager iteration alive: that autograd graph
+    pins the parameters' AccumulateGrad nodes, which live on the default stream; the capture then has to synchronise with
+    the default stream, and hipStreamEndCapture crashes (torch warns "The AccumulateGrad node's stream does not match")."""
 
     def __init__(self, model, fn, inputs, zero_grad, warmup=3):
         assert model.training and all(t is None or t.is_cuda for t in inputs)
+        import gc
+        gc.collect()                           # drop unreachable autograd graphs of earlier iterations (see above)
         self.model, self.fn = model, fn
         model.enable_device_keys(True)
         self.static = [None if t is None else t.clone() for t in inputs]
@@ -36,6 +42,7 @@ class GraphedStep:
                 zero_grad()
                 loss_dict, _ = fn(*self.static)
                 loss_dict["loss"].backward()
+                del loss_dict, _               # no autograd graph of a warm-up pass may outlive it (see the class docstring)
             if convops._pack_cache.entries:
                 convops._pack_cache.repack_all()   # builds the device-side pack table the captured launch will reuse
         main.wait_stream(side)

@@ -9,7 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--batch", "2", "--clip_len", "16384", "--steps", "2", "--warmup", "1", "--no_cpu_baseline", "--no_fp32"]
+SMALL = ["--batch", "2", "--clip_len", "16384", "--steps", "2", "--warmup", "1", "--no_cpu_baseline", "--no_fp32", "--no_graph"]
 
 
 def _run(args, env=None):
@@ -32,6 +32,15 @@ def test_single_gpu_line_has_the_contract_fields():
     assert d["n_gpus"] == 1 and d["unit"] == "utterances/s" and d["data"] == "synthetic" and d["vs_baseline"] is None
     assert d["config"]["workload"].startswith("configs[1]") and d["roofline"]["bound"] in ("mfma", "hbm")
     assert abs(d["value"] - 2 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]
+
+
+def test_hip_graph_leg_runs_in_a_child_process_and_reports():
+    """The secondary `hip_graph` object: the same step with forward + backward replayed from a captured graph, measured in a
+    child process so that a failure there cannot take the headline line down."""
+    d = _run([a for a in SMALL if a != "--no_graph"])
+    g = d["hip_graph"]
+    assert "error" not in g, g
+    assert g["unit"] == "utterances/s" and g["value"] > 0 and g["loss"] == g["loss"]
 
 
 def test_two_ranks_started_by_bench_itself():

@@ -54,7 +54,7 @@ def parse(argv=None):
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--no_kernel_events", action="store_true",
                    help="do not bracket kernels with HIP events in the timed region (no roofline objects)")
-    p.add_argument("--event_every", type=int, default=3,
+    p.add_argument("--event_every", type=int, default=5,
                    help="bracket every native call with HIP events on every N-th timed step (events serialise the "
                         "kernels around them: ~4 %% of the step when every step is instrumented)")
     p.add_argument("--cpu_clip_len", type=int, default=CLIP_LEN // 2,

@@ -308,11 +308,15 @@ int smt_melspec(const float* x, const float* window, const float* twiddle, const
 /* One resolution of MultiResolutionSpectralLoss (models/vqvae/losses.py:39-55) without materialising
  * the spectra.  fwd: partial [batch, frames, 2] = per-frame sums of ((|Y|-|Yh|) m)^2 and
  * ((log|Y| - log|Yh|) m)^2 (clamp 1e-5), m = frame mask from lens (losses.py:33-37).
- * bwd: dyh [batch, t] += adjoint of dL/dYh with coef [batch, 2] = upstream * 1/(2 B sqrt(S)) per term. */
+ * bwd: dyh [batch, t] = adjoint of dL/dYh with coef [batch, 2] = upstream * 1/(2 B sqrt(S)) per term (written, not
+ * accumulated).  The per-frame gradient rows go through `workspace` and are summed per sample in a fixed order: the result
+ * is bit-reproducible (no floating-point atomics). */
 int smt_stft_loss_fwd(const float* y, const float* yh, const int* lens, const float* window, const float* twiddle,
                       float* partial, int batch, int t, int n_fft, int hop, smt_stream_t stream);
+size_t smt_stft_loss_bwd_workspace_bytes(int batch, int t, int n_fft, int hop);
 int smt_stft_loss_bwd(const float* y, const float* yh, const int* lens, const float* window, const float* twiddle,
-                      const float* coef, float* dyh, int batch, int t, int n_fft, int hop, smt_stream_t stream);
+                      const float* coef, float* dyh, int batch, int t, int n_fft, int hop, void* workspace,
+                      size_t workspace_bytes, smt_stream_t stream);
 
 /* STFT.inverse (datasets/transforms.py:125-156): magnitude, phase [batch, n_fft/2+1, frames] ->
  * out [batch, (frames - 1) * hop + n_fft - 2 * ((n_fft - hop) / 2)]: inverse real FFT per frame, synthesis window,

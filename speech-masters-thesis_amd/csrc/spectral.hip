@@ -158,19 +158,22 @@ __global__ __launch_bounds__(256) void stft_loss_fwd_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------- loss backward ---
-// dyh += adjoint( dL/dYh ),  dL/d|Yh| = -c_lin[b] (|Y|-|Yh|) - c_log[b] (log|Y|-log|Yh|) / |Yh| [|Yh| > 1e-5]
+// dyh = adjoint( dL/dYh ),  dL/d|Yh| = -c_lin[b] (|Y|-|Yh|) - c_log[b] (log|Y|-log|Yh|) / |Yh| [|Yh| > 1e-5]
 // coef[b] = {c_lin, c_log} already contains the upstream gradient and the 1/(2 sqrt(S)) factors.
+// Two kernels: this one leaves every live frame's windowed time-domain gradient row in `rows` [B, frames, N]; the gather
+// kernel below sums, for every sample, the rows that overlap it IN A FIXED ORDER -- an overlap-add with f32 atomics (the
+// first version) made the gradient, and with it the whole train step, differ from run to run in the last bits.
 template <int N>
 __global__ __launch_bounds__(256) void stft_loss_bwd_kernel(const float* __restrict__ y, const float* __restrict__ yh,
                                                             const int* __restrict__ lens,
                                                             const float* __restrict__ window,
                                                             const cplx* __restrict__ tw, const float* __restrict__ coef,
-                                                            float* __restrict__ dyh, int T, int hop, int pad,
+                                                            float* __restrict__ rows, int T, int hop, int pad,
                                                             int frames) {
   __shared__ cplx buf[2][N];
   const int f = blockIdx.x, b = blockIdx.y;
   const int len = lens ? lens[b] : T;
-  if (!((N / 2 - pad + f * hop) < len)) return;  // masked frame: no gradient (block-uniform exit)
+  if (!((N / 2 - pad + f * hop) < len)) return;  // masked frame: no gradient (block-uniform exit); the gather skips its row
   const float* yb = y + (long long)b * T;
   const float* hb = yh + (long long)b * T;
   for (int n = threadIdx.x; n < N; n += 256) {
@@ -205,11 +208,34 @@ __global__ __launch_bounds__(256) void stft_loss_bwd_kernel(const float* __restr
   // x_grad[n] = w[n] * Re( sum_k G_k e^{+2 pi i k n / N} )
   cplx* other = (G == buf[0]) ? buf[1] : buf[0];
   const cplx* R = fft_lds<N>(G, other, tw, true);
-  float* db = dyh + (long long)b * T;
-  for (int n = threadIdx.x; n < N; n += 256) {
-    const float w = window[n];
-    if (w != 0.f) atomicAdd(db + reflect_index(f * hop + n - pad, T), w * R[n].x);
+  float* row = rows + ((long long)b * frames + f) * N;
+  for (int n = threadIdx.x; n < N; n += 256) row[n] = window[n] * R[n].x;
+}
+
+// dyh[b, i] = sum of rows[b, f, n] over the (f, n) whose padded position f hop + n - pad reflects onto sample i
+// (F.pad(mode="reflect"): p < 0 -> -p, p >= T -> 2 (T - 1) - p), live frames only, in the order: positions i, -i,
+// 2 (T - 1) - i, frames ascending inside each.
+__global__ __launch_bounds__(256) void stft_overlap_gather_kernel(const float* __restrict__ rows, const int* __restrict__ lens,
+                                                                  float* __restrict__ dyh, int T, int N, int hop, int pad,
+                                                                  int frames) {
+  const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (i >= T) return;
+  const int len = lens ? lens[b] : T;
+  const float* rb = rows + (long long)b * frames * N;
+  const int pmax = (frames - 1) * hop + N - 1 - pad;          // last padded position any frame touches
+  int cand[3] = {i, -i, 2 * (T - 1) - i};
+  const bool use[3] = {true, i >= 1 && i <= pad, i <= T - 2 && cand[2] <= pmax};
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    if (!use[c]) continue;
+    const int q = cand[c] + pad;                              // offset in the padded signal, >= 0
+    const int f_hi = min(frames - 1, q / hop);
+    const int f_lo = q - N + 1 > 0 ? (q - N + hop) / hop : 0; // ceil((q - N + 1) / hop)
+    for (int f = f_lo; f <= f_hi; ++f)
+      if ((N / 2 - pad + f * hop) < len) s += rb[(long long)f * N + (q - f * hop)];
   }
+  dyh[(long long)b * T + i] = s;
 }
 
 
@@ -353,18 +379,30 @@ extern "C" int smt_stft_loss_fwd(const float* y, const float* yh, const int* len
   return 0;
 }
 
+extern "C" size_t smt_stft_loss_bwd_workspace_bytes(int batch, int t, int n_fft, int hop) {
+  const int frames = stft_frames(t, n_fft, hop);
+  return frames <= 0 ? 0 : (size_t)batch * frames * n_fft * sizeof(float);
+}
+
 extern "C" int smt_stft_loss_bwd(const float* y, const float* yh, const int* lens, const float* window,
                                  const float* twiddle, const float* coef, float* dyh, int batch, int t, int n_fft,
-                                 int hop, smt_stream_t stream_) {
+                                 int hop, void* workspace, size_t workspace_bytes, smt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SMT_CHECK_ARG(y && yh && window && twiddle && coef && dyh, "smt_stft_loss_bwd: null pointer");
   const int pad = (n_fft - hop) / 2;
   const int frames = stft_frames(t, n_fft, hop);
-  if (batch == 0 || frames <= 0) return 0;
+  if (batch == 0 || t <= 0) return 0;
+  if (frames <= 0) { (void)hipMemsetAsync(dyh, 0, (size_t)batch * t * sizeof(float), stream); return 0; }
+  SMT_CHECK_ARG(t > pad, "smt_stft_loss_bwd: signal shorter than the reflect padding");
+  SMT_CHECK_ARG(workspace && workspace_bytes >= smt_stft_loss_bwd_workspace_bytes(batch, t, n_fft, hop),
+                "smt_stft_loss_bwd: workspace too small");
+  float* rows = (float*)workspace;
   dim3 grid(frames, batch);
   SMT_FFT_DISPATCH(n_fft, (stft_loss_bwd_kernel<N><<<grid, 256, 0, stream>>>(y, yh, lens, window, (const cplx*)twiddle,
-                                                                           coef, dyh, t, hop, pad, frames)));
+                                                                           coef, rows, t, hop, pad, frames)));
   SMT_CHECK_LAUNCH("stft_loss_bwd");
+  stft_overlap_gather_kernel<<<dim3((t + 255) / 256, batch), 256, 0, stream>>>(rows, lens, dyh, t, n_fft, hop, pad, frames);
+  SMT_CHECK_LAUNCH("stft_overlap_gather");
   return 0;
 }
 

@@ -68,8 +68,9 @@ _SIGNATURES = {
     "smt_stft_magnitude": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "smt_melspec": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr]),
     "smt_stft_loss_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "smt_stft_loss_bwd_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int]),
     "smt_stft_loss_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int,
-                                  c_ptr]),
+                                  c_ptr, c_size, c_ptr]),
     "smt_stft_inverse": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
     "smt_conv_out_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr,
                                  c_size, c_ptr]),

@@ -121,11 +121,13 @@ class _StftLoss(torch.autograd.Function):
         if not use_log:
             coef = coef * _const([1.0, 0.0], coef.device)
         coef = coef.contiguous().float()
-        dyh = torch.zeros_like(yh)
+        dyh = torch.empty_like(yh)
+        ws_bytes = N.lib().smt_stft_loss_bwd_workspace_bytes(b, t, n_fft, hop)
+        ws = torch.empty(max(int(ws_bytes), 16), dtype=torch.uint8, device=y.device)     # per-frame gradient rows
         with profiler.region("stft_loss_bwd", nbytes=3 * y.numel() * 4, bound="hbm"):
             N.check(N.lib().smt_stft_loss_bwd(N.ptr(y), N.ptr(yh), N.ptr(lens32), N.ptr(window), N.ptr(tw),
-                                              N.ptr(coef), N.ptr(dyh), b, t, n_fft, hop, N.stream_ptr()),
-                    "smt_stft_loss_bwd")
+                                              N.ptr(coef), N.ptr(dyh), b, t, n_fft, hop, N.ptr(ws), ws.numel(),
+                                              N.stream_ptr()), "smt_stft_loss_bwd")
         return None, dyh, None, None, None, None, None
 
 

@@ -180,3 +180,43 @@ def test_device_keys_and_graphed_step_reproduce_the_eager_vqvae_step(tmp_path):
     again = loss_of(m_gr)                        # (the codebook EMA has moved on by one forward: equal to ~1e-3, not bit for bit)
     assert abs(again - third_graph) <= 1e-3 * abs(third_graph), (again, third_graph)
     assert abs(third_graph - second_graph) >= 5 * abs(again - third_graph)      # stale packed weights would replay step 2's loss
+
+
+def test_vqvae_train_steps_are_bit_reproducible(tmp_path):
+    """Two runs of three full train steps (bf16 conv stacks, dropout on, ragged lengths, codebook EMA + revival, AdamW) from
+    the same seeds end with bit-identical losses, parameters and codebook: nothing on the step accumulates in floating point
+    in arrival order any more (weight-gradient slabs are reduced in a fixed order, the codebook statistics in 64-bit fixed
+    point, the spectral loss's overlap-add is a gather)."""
+    import train as trainlib
+    from oracle import vqvae_oracle as orc
+    from utils import config as C
+    from utils.commons import get_model, get_optimizer
+    cfg = C.merge(C.load(os.path.join(PKG, "configs/models/vqvae.yaml")),
+                  C.load(os.path.join(PKG, "configs/datasets/synthetic_ljspeech.yaml")),
+                  C.create({"train": {"batch_size": 3, "n_gpus": 1, "ema": False, "grad_clip_norm": None, "seed": 0,
+                                      "log_dir": str(tmp_path), "total_epochs": 1}}))
+    cfg.model.update(C.create(dict(width=64, emb_width=128, l_bins=256, multipliers=[1, 1, 1], compute_dtype="bf16")))
+    cfg.model.loss.linf_topk = 256
+    dev = torch.device("cuda", 0)
+    x = orc.synthetic_clip_batch(3, 32768, 9).cuda()
+    lens = torch.tensor([32768, 20000, 27001]).cuda()
+    batch = [None, None, None, None, x, lens, None]
+
+    def run():
+        torch.manual_seed(3)
+        model, ema = get_model(C.create(cfg.to_dict()), dev)
+        opt, sched = get_optimizer(cfg, model)
+        model.train()
+        losses = []
+        for step in range(3):
+            loss_dict, _ = trainlib.train_step(global_step=step, batch=batch, config=cfg, model=model, ema=ema, optimizer=opt,
+                                               scheduler=sched, device=dev)
+            losses.append(float(loss_dict["loss"].detach()))
+        blk = model.bottleneck.level_blocks[0]
+        return losses, [p.detach().clone() for p in model.parameters()], blk.k.clone(), blk.k_sum.clone()
+
+    l1, p1, k1, s1 = run()
+    l2, p2, k2, s2 = run()
+    assert l1 == l2, (l1, l2)
+    assert torch.equal(k1, k2) and torch.equal(s1, s2)
+    assert all(torch.equal(a, b) for a, b in zip(p1, p2))

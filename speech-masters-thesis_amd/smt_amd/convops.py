@@ -115,6 +115,7 @@ class _PackCache:
         self.order = []          # keys in table order
         self.table = None        # (table_dev, block_entry_dev, block_local_dev, n_blocks, n_rows)
         self.device = None
+        self.dirty = False       # set by mark_packed_weights_dirty(): repack on the next use whatever the versions say
 
     def get(self, key, build):
         e = self.entries.get(key)
@@ -128,7 +129,7 @@ class _PackCache:
             self._launch([e])                       # first use: pack just this operand
             e["versions"] = [w._version for w, _ in e["parts"]]
             return e["dst"]
-        if e["versions"] != [w._version for w, _ in e["parts"]]:
+        if self.dirty or e["versions"] != [w._version for w, _ in e["parts"]]:
             self.repack_all()
         return e["dst"]
 
@@ -166,9 +167,22 @@ class _PackCache:
                 self.table[dev] = self._launch(es, self.table.get(dev))
             for e in es:
                 e["versions"] = [w._version for w, _ in e["parts"]]
+        self.dirty = False
 
 
 _pack_cache = _PackCache()
+
+
+def mark_packed_weights_dirty(*_args, **_kwargs):
+    """The parameters have (or may have) changed: repack every operand copy at its next use (one batched launch).
+
+    ``Tensor._version`` alone is NOT enough to notice an optimizer step: torch's fused AdamW (``fused=True``, what
+    utils/commons.get_optimizer builds) updates the parameters without moving their version counters on this torch / ROCm
+    build, and the convolutions would go on multiplying with the weights of step 0 while the optimizer moved the fp32 masters
+    (found in round 2 when a captured graph, which repacks on every replay, stopped agreeing with the eager step after the
+    first update).  get_optimizer registers this function as a step post-hook; any other writer of parameters calls it, or
+    invalidate_packed_weights(), itself."""
+    _pack_cache.dirty = True
 
 
 def invalidate_packed_weights():

@@ -116,12 +116,8 @@ def test_resume_keeps_the_trained_codebook(tmp_path):
 
 def test_device_keys_and_graphed_step_reproduce_the_eager_vqvae_step(tmp_path):
     """dropout keys from device memory + forward/backward in a hipGraph, on a small bf16 VQ-VAE (dropout
-    on, ragged).  The checks are the ones that are deterministic (gradients carry f32-atomic noise from the spectral loss's
-    overlap-add, which Adam's first steps amplify, so multi-step loss curves of two runs of ANY mode drift apart):
-    (1) from equal weights the first loss is bit-identical with keys by value, keys from the device, and a graph replay;
-    (2) a second pass over the same weights draws NEW masks, the same ones eagerly and in the graph;
-    (3) after an optimizer step the replay matches an eager forward of the same model at the same counter -- the graph sees
-        the updated weights (the packed copies are refreshed inside it)."""
+    on, ragged).  The train step being bit-reproducible, three optimizer steps with keys by value, with keys from the device
+    and with graph replays must give bit-identical losses -- same masks, same kernels, same weights all the way."""
     from oracle import vqvae_oracle as orc
     from smt_amd.graph import GraphedStep
     from utils import config as C
@@ -138,48 +134,41 @@ def test_device_keys_and_graphed_step_reproduce_the_eager_vqvae_step(tmp_path):
     lens = torch.tensor([16384, 12288]).cuda()
     batch = [None, None, None, None, x, lens, None]
 
-    def fresh():
+    def run(mode):
         torch.manual_seed(0)
         model, _ = get_model(C.create(cfg.to_dict()), dev)
         opt, sched = get_optimizer(cfg, model)
         model.train()
         first, _ = model.supervised_step(batch)   # the first forward initialises the codebook from the batch (host-side branch)
         first["loss"].backward()                  # ... and the first backward creates the packed data-gradient weights
+        del first
         opt.zero_grad(set_to_none=True)
         model._drop_seed = 50
-        return model, opt, sched
+        graph = None
+        if mode == "device":
+            model.enable_device_keys(True)
+        if mode == "graph":
+            graph = GraphedStep(model, lambda *slots: model.supervised_step(list(slots)), batch,
+                                lambda: opt.zero_grad(set_to_none=True), warmup=0)
+        losses = []
+        for _ in range(3):
+            if graph is not None:
+                loss_dict, _ = graph.replay(*batch)
+            else:
+                opt.zero_grad(set_to_none=True)
+                loss_dict, _ = model.supervised_step(batch)
+                loss_dict["loss"].backward()
+            opt.step(); sched.step()
+            losses.append(float(loss_dict["loss"].detach()))
+            del loss_dict
+        return losses, model._drop_seed, (int(model._seed_dev) if model._seed_dev is not None else None)
 
-    def loss_of(model):
-        return float(model.supervised_step(batch)[0]["loss"].detach())
-
-    by_value = loss_of(fresh()[0])
-    m_dev, o_dev, _ = fresh()
-    m_dev.enable_device_keys(True)
-    m_gr, o_gr, _ = fresh()
-    graph = GraphedStep(m_gr, lambda *slots: m_gr.supervised_step(list(slots)), batch, lambda: o_gr.zero_grad(set_to_none=True),
-                        warmup=0)
-
-    def replay():
-        return float(graph.replay(*batch)[0]["loss"])
-
-    # (1)
-    o_dev.zero_grad(set_to_none=True)
-    out, _ = m_dev.supervised_step(batch)
-    out["loss"].backward()
-    first_dev, first_graph = float(out["loss"].detach()), replay()
-    assert by_value == first_dev == first_graph
-    assert m_dev._drop_seed == m_gr._drop_seed == int(m_dev._seed_dev) == int(m_gr._seed_dev) == 51
-    # (2)
-    second_dev, second_graph = loss_of(m_dev), replay()
-    assert second_dev == second_graph and second_dev != first_dev and int(m_gr._seed_dev) == 52
-    # (3)
-    o_gr.step()
-    third_graph = replay()
-    m_gr._drop_seed -= 1
-    m_gr._seed_dev.sub_(1)                       # rewind the counter: the same masks once more, eagerly
-    again = loss_of(m_gr)                        # (the codebook EMA has moved on by one forward: equal to ~1e-3, not bit for bit)
-    assert abs(again - third_graph) <= 1e-3 * abs(third_graph), (again, third_graph)
-    assert abs(third_graph - second_graph) >= 5 * abs(again - third_graph)      # stale packed weights would replay step 2's loss
+    by_value, seed_v, _ = run("value")
+    from_device, seed_d, dev_d = run("device")
+    graphed, seed_g, dev_g = run("graph")
+    assert seed_v == seed_d == dev_d == seed_g == dev_g == 53 and len(set(by_value)) == 3
+    assert from_device == by_value, (from_device, by_value)
+    assert graphed == by_value, (graphed, by_value)
 
 
 def test_vqvae_train_steps_are_bit_reproducible(tmp_path):
@@ -220,3 +209,43 @@ def test_vqvae_train_steps_are_bit_reproducible(tmp_path):
     assert l1 == l2, (l1, l2)
     assert torch.equal(k1, k2) and torch.equal(s1, s2)
     assert all(torch.equal(a, b) for a, b in zip(p1, p2))
+
+
+
+def test_packed_conv_weights_follow_the_optimizer(tmp_path):
+    """Regression (round 2): fused AdamW does not move Tensor._version, so a cache keyed on versions alone kept the
+    convolutions on the weights of step 0.  Three eager train steps must equal three steps with the packed copies thrown
+    away before every forward, bit for bit (the step is reproducible), and the loss must actually move."""
+    import train as trainlib
+    from oracle import vqvae_oracle as orc
+    from smt_amd import convops
+    from utils import config as C
+    from utils.commons import get_model, get_optimizer
+    cfg = C.merge(C.load(os.path.join(PKG, "configs/models/vqvae.yaml")),
+                  C.load(os.path.join(PKG, "configs/datasets/synthetic_ljspeech.yaml")),
+                  C.create({"train": {"batch_size": 2, "n_gpus": 1, "ema": False, "grad_clip_norm": None, "seed": 0,
+                                      "log_dir": str(tmp_path), "total_epochs": 1}}))
+    cfg.model.update(C.create(dict(width=64, emb_width=128, l_bins=64, multipliers=[1, 1, 1], compute_dtype="bf16")))
+    cfg.model.loss.linf_topk = 128
+    dev = torch.device("cuda", 0)
+    x = orc.synthetic_clip_batch(2, 16384, 5).cuda()
+    lens = torch.tensor([16384, 12288]).cuda()
+    batch = [None, None, None, None, x, lens, None]
+
+    def run(invalidate):
+        torch.manual_seed(0)
+        model, ema = get_model(C.create(cfg.to_dict()), dev)
+        opt, sched = get_optimizer(cfg, model)
+        model.train()
+        losses = []
+        for step in range(3):
+            if invalidate:
+                convops.invalidate_packed_weights()
+            loss_dict, _ = trainlib.train_step(global_step=step, batch=batch, config=cfg, model=model, ema=ema, optimizer=opt,
+                                               scheduler=sched, device=dev)
+            losses.append(float(loss_dict["loss"].detach()))
+        return losses
+
+    plain, fresh_packs = run(False), run(True)
+    assert plain == fresh_packs, (plain, fresh_packs)
+    assert abs(plain[1] - plain[0]) > 1e-3 * abs(plain[0])          # the first update is visible in the second loss

@@ -103,9 +103,10 @@ class _PackCache:
     """Packed operand copies of the weights, repacked in ONE table-driven launch when the weights have changed.
 
     Every conv needs its fp32 torch-layout weight in operand layout (twice: forward and data-gradient layouts).
-    Packing per use costs ~390 tiny launches per train step.  Parameters keep their storage across optimiser steps
-    and bump ``_version`` when updated in place, so each (weights, layout) pair gets a persistent destination and a
-    row in a device-side table; the first use after an update repacks ALL rows with smt_pack_weights_batched.
+    Packing per use costs ~390 tiny launches per train step.  Parameters keep their storage across optimiser steps, so
+    each (weights, layout) pair gets a persistent destination and a row in a device-side table; the first use after an
+    update -- announced by mark_packed_weights_dirty() (the optimizer step post-hook) or noticed through a moved
+    ``_version`` -- repacks ALL rows with smt_pack_weights_batched.
     Source tensors are held strongly so that an address can never be reused by a different tensor behind a key."""
 
     MAX_ENTRIES = 8192
@@ -186,10 +187,10 @@ def mark_packed_weights_dirty(*_args, **_kwargs):
 
 
 def invalidate_packed_weights():
-    """Forget every packed operand copy.  The cache notices in-place updates through ``Tensor._version`` (optimiser
-    steps, ``copy_``, ``broadcast``); writes that bypass the version counter -- ``p.data.copy_(...)`` as in the
-    reference's ``EMA.swap`` (models/ema.py:60-66), or a foreign kernel writing the parameter by pointer -- do not
-    bump it, so such writers call this afterwards (``load_checkpoint`` and ``EMA.swap`` do)."""
+    """Forget every packed operand copy.  The cache notices updates through the optimizer hook
+    (mark_packed_weights_dirty) and through ``Tensor._version`` (``copy_``, ``broadcast``); writes that bypass both --
+    ``p.data.copy_(...)`` as in the reference's ``EMA.swap`` (models/ema.py:60-66), or a foreign kernel writing the
+    parameter by pointer -- call this (or the hook) afterwards (``load_checkpoint`` and ``EMA.swap`` do)."""
     _pack_cache.entries.clear()
     _pack_cache.order.clear()
     _pack_cache.table = None

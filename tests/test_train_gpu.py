@@ -249,3 +249,33 @@ def test_packed_conv_weights_follow_the_optimizer(tmp_path):
     plain, fresh_packs = run(False), run(True)
     assert plain == fresh_packs, (plain, fresh_packs)
     assert abs(plain[1] - plain[0]) > 1e-3 * abs(plain[0])          # the first update is visible in the second loss
+
+
+def test_training_on_one_batch_drives_the_loss_down(tmp_path):
+    """End-to-end sanity that the optimizer's updates reach every kernel: 60 train steps on one ragged batch (bf16 conv
+    stacks, dropout on, AdamW) must cut the training loss by a large factor -- measured: 4193 -> 1930, the spectral term
+    dominating.  (With stale packed conv weights -- the bug fixed in round 2 -- it stayed within 1 % of its starting value.)"""
+    import train as trainlib
+    from oracle import vqvae_oracle as orc
+    from utils import config as C
+    from utils.commons import get_model, get_optimizer
+    cfg = C.merge(C.load(os.path.join(PKG, "configs/models/vqvae.yaml")),
+                  C.load(os.path.join(PKG, "configs/datasets/synthetic_ljspeech.yaml")),
+                  C.create({"train": {"batch_size": 3, "n_gpus": 1, "ema": False, "grad_clip_norm": None, "seed": 0,
+                                      "log_dir": str(tmp_path), "total_epochs": 1}}))
+    cfg.model.update(C.create(dict(width=64, emb_width=128, l_bins=256, multipliers=[1, 1, 1], compute_dtype="bf16")))
+    cfg.model.loss.linf_topk = 256
+    dev = torch.device("cuda", 0)
+    x = orc.synthetic_clip_batch(3, 32768, 9).cuda()
+    lens = torch.tensor([32768, 20000, 27001]).cuda()
+    batch = [None, None, None, None, x, lens, None]
+    torch.manual_seed(0)
+    model, ema = get_model(cfg, dev)
+    opt, sched = get_optimizer(cfg, model)
+    model.train()
+    history = []
+    for step in range(60):
+        loss_dict, _ = trainlib.train_step(global_step=step, batch=batch, config=cfg, model=model, ema=ema, optimizer=opt,
+                                           scheduler=sched, device=dev)
+        history.append(float(loss_dict["loss"].detach()))
+    assert min(history[-5:]) < 0.6 * history[0], (history[0], history[-5:])

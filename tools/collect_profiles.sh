@@ -19,7 +19,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o w -
 python $R/tools/pmc_traffic.py $O/fetch/f_counter_collection.csv $O/write/w_counter_collection.csv $O/pmc_traffic
 rm -f $O/fetch/*kernel_trace.csv $O/write/*kernel_trace.csv
 echo "[5/5] PMC MFMA busy + clock"; date
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/mfma -o m -- python $R/bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_kernel_events --no_fp32 > $O/mfma.json 2> $O/mfma.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/mfma -o m -- python $R/bench.py --steps 1 --warmup 3 --no_cpu_baseline --no_kernel_events --no_fp32 > $O/mfma.json 2> $O/mfma.err
 python $R/tools/pmc_mfma.py $O/mfma/m_counter_collection.csv $O/mfma/m_kernel_trace.csv $O/pmc_mfma
 rm -f $O/mfma/*kernel_trace.csv $O/mfma/m_counter_collection.csv
 echo "[6/6] TransformerLM workload: bench line + kernel stats"; date

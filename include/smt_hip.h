@@ -348,7 +348,7 @@ int smt_lm_embed_bwd(const int64_t* tokens, const float* dout, float* demb, int 
                      smt_stream_t stream);
 
 /* Multi-head self-attention core of nn.MultiheadAttention as the reference calls it (:110-111,117: additive causal
- * mask triu(-inf, 1) plus the key-padding mask ~sequence_mask(lens)): head dim 32, len <= 512.
+ * mask triu(-inf, 1) plus the key-padding mask ~sequence_mask(lens)): head dim 32, len * 3 * heads * 32 < 2^31.
  *   qkv [batch, len, 3*heads*32] = (q | k | v) rows as in_proj produces them;  lens [batch] int32 or NULL
  *   ctx [batch, len, heads*32] = dropout(softmax(q k^T / sqrt(32) + masks)) v;   lse [batch, heads, len]: scratch between
  *   the forward and the backward call (log2 of the sum of 2^(score * log2 e): the kernels work in base 2)

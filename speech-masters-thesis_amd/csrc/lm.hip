@@ -9,7 +9,7 @@
 //   lm_bias_relu    dropout(relu(h + b))  in place                                              (linear1 -> activation -> dropout)
 //   lm_ce           masked mean cross-entropy + accuracy over the next-token logits              (transformer_lm.py:121-128)
 //
-// Activations are [B, L, C] fp32 rows (the fp32 parity path; L <= 512, head dim 32).  Dropout masks come from the
+// Activations are [B, L, C] fp32 rows (the fp32 parity path; head dim 32, any L with L * 3 * heads * 32 < 2^31).  Dropout masks come from the
 // counter-based generator of include/smt_hip.h ("dropout"): keep(i) of the element's linear index under a per-site key,
 // so the backward kernels recompute them.
 #include <algorithm>
@@ -56,7 +56,10 @@ __global__ __launch_bounds__(256) void lm_embed_bwd_kernel(const long long* __re
 // staged in LDS with four lanes per query row was bound by the 128 B/clk LDS pipe -- every lane pulling the same 256 bytes
 // per key -- at 48 / 50 / 58 us for forward / dq / dkv at 8 x 16 x 258; broadcasting the rows through scalar loads instead
 // was bound by the scalar cache's miss latency, 70 / 50 / 63 us.)
-constexpr int LM_DH = 32, LM_MAXL = 512;
+constexpr int LM_DH = 32;
+// Longest sequence: the kernels walk the keys / queries in 32-row blocks (online softmax), so the only limit is the 32-bit
+// element offset inside one batch item's qkv block, len * 3 * heads * 32 < 2^31 (the reference's max_len is 5000).
+static inline bool lm_len_ok(int len, int heads) { return (long long)len * 3 * heads * LM_DH < (1ll << 31); }
 
 // The attention kernels run on the f32-input matrix pipe (v_mfma_f32_32x32x2_f32: exact f32 products and sums at the
 // VALU's FLOP rate, but one operand register per 32 FMAs instead of one LDS read per FMA).  A workgroup owns 32 rows of
@@ -570,7 +573,7 @@ extern "C" int smt_lm_attention_fwd(const float* qkv, const int* lens, float* ct
   hipStream_t stream = (hipStream_t)stream_;
   if (batch <= 0 || len <= 0) return 0;
   SMT_CHECK_ARG(qkv && ctx && lse, "smt_lm_attention_fwd: null pointer");
-  SMT_CHECK_ARG(len <= LM_MAXL && heads >= 1, "smt_lm_attention_fwd: len must be <= %d (got %d)", LM_MAXL, len);
+  SMT_CHECK_ARG(heads >= 1 && lm_len_ok(len, heads), "smt_lm_attention_fwd: len * 3 * heads * 32 must be < 2^31 (len %d, heads %d)", len, heads);
   SMT_CHECK_ARG((long long)batch * heads <= 65535, "smt_lm_attention_fwd: batch * heads must be <= 65535");
   lm_attn_fwd_kernel<<<dim3((len + 31) / 32, batch * heads), 256, 0, stream>>>(qkv, lens, ctx, lse, len, heads, causal, drop_key, drop_key_dev,
                                                                            drop_thresh16, drop_scale);
@@ -584,7 +587,7 @@ extern "C" int smt_lm_attention_bwd(const float* qkv, const int* lens, const flo
   hipStream_t stream = (hipStream_t)stream_;
   if (batch <= 0 || len <= 0) return 0;
   SMT_CHECK_ARG(qkv && ctx && lse && dctx && dqkv && delta, "smt_lm_attention_bwd: null pointer");
-  SMT_CHECK_ARG(len <= LM_MAXL && heads >= 1, "smt_lm_attention_bwd: len must be <= %d (got %d)", LM_MAXL, len);
+  SMT_CHECK_ARG(heads >= 1 && lm_len_ok(len, heads), "smt_lm_attention_bwd: len * 3 * heads * 32 must be < 2^31 (len %d, heads %d)", len, heads);
   SMT_CHECK_ARG((long long)batch * heads <= 65535, "smt_lm_attention_bwd: batch * heads must be <= 65535");
   const dim3 grid((len + 31) / 32, batch * heads);
   lm_attn_dq_kernel<<<grid, 256, 0, stream>>>(qkv, lens, ctx, lse, dctx, dqkv, delta, len, heads, causal, drop_key, drop_key_dev, drop_thresh16,

@@ -63,7 +63,9 @@ __global__ __launch_bounds__(MAS_NT) void maximum_path_kernel(const float* __res
   if (tid == 0) {
     int index = first_col_count - 1;                          // mask[:, :, 0].sum(1) - 1
     for (int j = t_y - 1; j >= 0; --j) {
-      const int p = index < 0 ? index + t_x : index;          // numpy wraps a negative index
+      const int p = index < 0 ? index + t_x : index;          // numpy wraps a negative index ONCE ...
+      if (p < 0 || p >= t_x) break;                           // ... and raises IndexError beyond that (NaN likelihoods, an empty first
+                                                              // mask column with t_y > t_x): stop here, the rest of the path stays 0
       const unsigned long long mw = maskb[(size_t)j * words + (p >> 6)], dw = dirb[(size_t)j * words + (p >> 6)];
       const int mbit = (int)((mw >> (p & 63)) & 1), dbit = (int)((dw >> (p & 63)) & 1);
       if (mbit) out[(size_t)p * t_y + j] = 1.f;               // path * mask

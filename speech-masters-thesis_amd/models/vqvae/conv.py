@@ -38,6 +38,7 @@ class EncoderConvBlock(nn.Module):
         self.n_sites = down_t * 2 * depth
         self.act_dtype = torch.float32
 
+    @convops.forward_scope
     def forward(self, x, lens, drop_seed=0):
         s = self.stride_t
         for i in range(self.down_t):
@@ -71,6 +72,7 @@ class DecoderConvBlock(nn.Module):
         self.blocks = nn.ModuleList(blocks)
         self.n_sites = down_t * 2 * depth
 
+    @convops.forward_scope
     def forward(self, x, lens, drop_seed=0):
         s = self.stride_t
         if self.down_t > 0:

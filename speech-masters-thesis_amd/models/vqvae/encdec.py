@@ -23,6 +23,7 @@ class Encoder(nn.Module):
         self.level_blocks = nn.ModuleList(stages)
         self.n_sites = base - site_base
 
+    @convops.forward_scope
     def forward(self, x, lens, drop_seed=0):
         """x: [B, T] fp32 waveform when input_emb_width == 1, else [B, T, C]."""
         b, t = x.shape[0], x.shape[1]
@@ -51,6 +52,7 @@ class Decoder(nn.Module):
         self.out = ConvParams(output_emb_width, input_emb_width, 1)
         self.n_sites = base - site_base
 
+    @convops.forward_scope
     def forward(self, x, lens, drop_seed=0):
         b, t, c = x.shape
         assert c == self.output_emb_width

@@ -66,6 +66,7 @@ class GatedHiFiBlock(nn.Module):
         self.blocks = nn.ModuleList(branches)
         self.gate = ConvParams(n_in, n_in, 1, zero=zero_out)
 
+    @convops.forward_scope
     def forward(self, x, lens, drop_seed=0):
         """x [B, T, n_in]; lens [B] valid lengths (the block's row mask)."""
         if self.res_scale != 1.0:

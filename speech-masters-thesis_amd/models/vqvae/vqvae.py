@@ -9,6 +9,7 @@ tools read the mutated config.  Internally activations are channels-last [B, T, 
 import torch
 import torch.nn as nn
 
+from smt_amd import convops
 from models.base import WaveformReconstructionModel
 from models.vqvae.bottleneck import Bottleneck
 from models.vqvae.encdec import Decoder, Encoder
@@ -70,7 +71,6 @@ class VQVAE(WaveformReconstructionModel):
         dev = next(self.parameters()).device
         self._seed_dev = torch.tensor([self._drop_seed & 0x7FFFFFFF], dtype=torch.int32, device=dev)
         self._keys_dev = torch.zeros(max(8, self._n_sites + 8), dtype=torch.int32, device=dev)
-        from smt_amd import convops
         convops.make_device_keys(self._seed_dev, self._keys_dev)
 
     # Checkpoints written by the reference carry the six DFT-basis buffers of the loss
@@ -79,13 +79,13 @@ class VQVAE(WaveformReconstructionModel):
         state_dict = {k: v for k, v in state_dict.items() if not k.endswith("_basis")}
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
+    @convops.forward_scope
     def forward(self, x, x_lengths, speaker=None, **vq_kwargs):
         """x [B, 1, T] float in [-1, 1]; x_lengths [B] -> (loss_dict, vq metrics)."""
         b, c, t = x.shape
         assert c == 1
         lens = x_lengths.to(torch.int32)
         self._drop_seed += 1
-        from smt_amd import convops
         if self._keys_dev is not None:                 # the same counter on the device, and this step's keys derived from it
             self._seed_dev.add_(1)
             convops.make_device_keys(self._seed_dev, self._keys_dev)

@@ -81,9 +81,7 @@ def get_optimizer(config, model):
                                     weight_decay=float(opt.weight_decay))
     else:
         raise ValueError(f"Didn't recognize optimizer name {opt.name}")
-    # the packed operand copies of the conv weights must follow every update: fused AdamW does not move Tensor._version
-    from smt_amd import convops
-    optimizer.register_step_post_hook(convops.mark_packed_weights_dirty)
+    # (the packed operand copies of the conv weights follow every update by themselves: smt_amd.convops.training_forward)
     sched = config.get("scheduler", None)
     from utils import lr_scheduler as S
     if not sched:

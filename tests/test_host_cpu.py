@@ -167,3 +167,54 @@ def test_optimizer_scheduler_ema_and_checkpoint_layout(tmp_path):
     accumulate_stats(2, {"loss": torch.tensor(4.0), "loss_x": torch.tensor(2.0), "yh": torch.zeros(3)},
                      {"fit": torch.tensor(1.0)}, losses, metrics)
     assert dict(losses) == {"loss": 2.0, "loss_x": 1.0} and dict(metrics) == {"fit": 0.5}
+
+
+def test_training_forward_scope_marks_packed_weights_stale_once_per_pass():
+    """smt_amd.convops.training_forward: the outermost scope of a TRAINING forward marks the packed operand copies stale
+    (one repack per pass), nested scopes and eval-mode scopes do not; every torch optimizer's step does, whoever built it."""
+    import torch
+    from smt_amd import convops
+    c = convops._pack_cache
+    g0 = c.generation
+    with convops.training_forward(True):
+        with convops.training_forward(True):
+            pass
+        with convops.training_forward(True):
+            pass
+    assert c.generation == g0 + 1 and c.dirty
+    with convops.training_forward(False):
+        with convops.training_forward(True):      # a training sub-module inside an eval-mode parent still refreshes
+            pass
+    assert c.generation == g0 + 2
+    with convops.training_forward(False):
+        pass
+    assert c.generation == g0 + 2
+    p = torch.nn.Parameter(torch.zeros(3))
+    p.grad = torch.ones(3)
+    torch.optim.SGD([p], lr=0.1).step()           # an optimizer nobody registered anything on
+    assert c.generation == g0 + 3
+
+    class M(torch.nn.Module):
+        @convops.forward_scope
+        def forward(self, x):
+            return x + 1
+    m = M()
+    m(torch.zeros(1))
+    assert c.generation == g0 + 4
+    m.eval()
+    m(torch.zeros(1))
+    assert c.generation == g0 + 4
+
+
+def test_stale_autograd_graph_probe():
+    """smt_amd.graph.stale_autograd_graphs: a parameter whose AccumulateGrad node is held by a live graph of an earlier
+    iteration is reported; once that graph is gone it is not (no GPU needed: the probe runs no kernel)."""
+    import torch
+    from smt_amd.graph import stale_autograd_graphs
+    params = [torch.nn.Parameter(torch.ones(3)), torch.nn.Parameter(torch.ones(2)), torch.zeros(2)]
+    assert stale_autograd_graphs(params) == []
+    loss = (params[1] * 2).sum()
+    assert stale_autograd_graphs(params) == [1]
+    assert stale_autograd_graphs(params) == [1]           # the probe leaves no trace of its own
+    del loss
+    assert stale_autograd_graphs(params) == []

@@ -46,7 +46,8 @@ def test_embedding_kernel(p):
 
 
 @pytest.mark.parametrize("causal,ragged,p,b,l,h", [(True, True, 0.0, 3, 21, 2), (True, True, 0.1, 2, 70, 4), (False, False, 0.0, 2, 9, 2),
-                                                  (True, False, 0.1, 1, 258, 16), (True, True, 0.0, 2, 300, 1)])
+                                                  (True, False, 0.1, 1, 258, 16), (True, True, 0.0, 2, 300, 1),
+                                                  (True, True, 0.1, 2, 513, 2), (False, True, 0.0, 1, 1030, 1)])
 def test_attention_kernel_forward_and_backward(causal, ragged, p, b, l, h):
     from smt_amd import lm as K
     g = torch.Generator().manual_seed(l)
@@ -242,6 +243,9 @@ def test_eval_reconstructs_audio_from_the_argmax_codes_and_sample_runs(tmp_path)
     audio, q = model.sample(batch_size=3, n_steps=6, device=DEV, sigma=1.0)
     assert q.shape == (3, 6) and int(q.min()) >= 0 and int(q.max()) < 16 and audio.shape == (3, 6 * 128)
     assert torch.isfinite(audio).all()
+    # the script's default --n_steps (1024, as in the reference) walks prefixes longer than 512 tokens
+    audio, q = model.sample(batch_size=1, n_steps=520, device=DEV, sigma=1.0)
+    assert q.shape == (1, 520) and audio.shape == (1, 520 * 128) and torch.isfinite(audio).all()
 
 
 def test_sample_step_is_the_uncausal_forward_of_the_reference(tmp_path):
@@ -389,8 +393,7 @@ def test_kernels_accept_empty_batches_and_reject_bad_shapes():
     assert K.add_layer_norm(torch.empty(0, 64, device=DEV), None, torch.ones(64, device=DEV), torch.zeros(64, device=DEV)).shape == (0, 64)
     with pytest.raises(AssertionError, match="head dim 32"):
         K.attention(torch.randn(1, 4, 3 * 48, device=DEV), None, 1)
-    with pytest.raises(RuntimeError, match="len must be <= 512"):
-        K.attention(torch.randn(1, 513, 3 * 32, device=DEV), None, 1)
+    assert K.attention(torch.randn(1, 513, 3 * 32, device=DEV), None, 1).shape == (1, 513, 32)      # no 512-token limit
     assert N.lib().smt_lm_add_ln_bwd_workspace_bytes(0, 512) == 0
 
 

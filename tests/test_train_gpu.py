@@ -251,6 +251,112 @@ def test_packed_conv_weights_follow_the_optimizer(tmp_path):
     assert abs(plain[1] - plain[0]) > 1e-3 * abs(plain[0])          # the first update is visible in the second loss
 
 
+def test_an_optimizer_built_by_the_caller_trains_the_same_weights(tmp_path):
+    """correctness of the packed conv weights is a property of the model, not a contract with
+    get_optimizer.  Three train steps with a plain ``torch.optim.AdamW(model.parameters(), fused=True)`` built HERE -- the way
+    the reference's utils/commons.get_optimizer (commons.py:126-134) or a notebook would -- equal three steps through this
+    build's get_optimizer bit for bit, and so do three steps whose parameters are moved by a raw ``p.data`` write that no
+    hook and no version counter can see."""
+    from oracle import vqvae_oracle as orc
+    from smt_amd import convops
+    from utils import config as C
+    from utils.commons import get_model, get_optimizer
+    cfg = C.merge(C.load(os.path.join(PKG, "configs/models/vqvae.yaml")),
+                  C.load(os.path.join(PKG, "configs/datasets/synthetic_ljspeech.yaml")),
+                  C.create({"train": {"batch_size": 2, "n_gpus": 1, "ema": False, "grad_clip_norm": None, "seed": 0,
+                                      "log_dir": str(tmp_path), "total_epochs": 1}}))
+    cfg.model.update(C.create(dict(width=64, emb_width=128, l_bins=64, multipliers=[1, 1, 1], compute_dtype="bf16")))
+    cfg.model.loss.linf_topk = 128
+    dev = torch.device("cuda", 0)
+    x = orc.synthetic_clip_batch(2, 16384, 5).cuda()
+    lens = torch.tensor([16384, 12288]).cuda()
+    batch = [None, None, None, None, x, lens, None]
+
+    def run(mode):
+        torch.manual_seed(0)
+        model, _ = get_model(C.create(cfg.to_dict()), dev)
+        if mode == "factory":
+            opt, _ = get_optimizer(cfg, model)
+        else:
+            o = cfg.optimizer
+            opt = torch.optim.AdamW(model.parameters(), lr=float(o.lr), betas=tuple(float(b) for b in o.betas),
+                                    weight_decay=float(o.weight_decay), eps=float(o.eps), fused=True)
+        model.train()
+        losses = []
+        for _ in range(3):
+            opt.zero_grad()
+            loss_dict, _ = model.supervised_step(batch)
+            loss_dict["loss"].backward()
+            if mode == "raw":                 # the update applied behind torch's back: p.data, no version bump, no hook
+                shadow = [p.detach().clone() for p in model.parameters()]
+                opt.step()
+                new = [p.detach().clone() for p in model.parameters()]
+                for p, old in zip(model.parameters(), shadow):
+                    p.data.copy_(old)
+                convops._pack_cache.dirty = False       # pretend nobody told the cache anything
+                for p, n in zip(model.parameters(), new):
+                    p.data.copy_(n)
+                convops._pack_cache.dirty = False
+            else:
+                opt.step()
+            losses.append(float(loss_dict["loss"].detach()))
+        return losses, [p.detach().clone() for p in model.parameters()]
+
+    (l_fac, p_fac), (l_own, p_own), (l_raw, p_raw) = run("factory"), run("own"), run("raw")
+    assert l_own == l_fac and l_raw == l_fac, (l_fac, l_own, l_raw)
+    assert all(torch.equal(a, b) for a, b in zip(p_fac, p_own)) and all(torch.equal(a, b) for a, b in zip(p_fac, p_raw))
+    assert abs(l_fac[1] - l_fac[0]) > 1e-3 * abs(l_fac[0])          # the first update is visible in the second loss
+
+
+def test_graphed_step_refuses_a_stale_autograd_graph_and_stale_packs(tmp_path):
+    """GraphedStep raises instead of taking the process down.  Specification = the failure recorded in
+    round 2 (gpurun_out/amdlog.txt: a live loss of an earlier eager iteration pins the AccumulateGrad nodes to the default
+    stream; hipStreamEndCapture segfaults).  Also ADVICE r02: a graph replayed after the packed weights it points at were
+    thrown away (EMA.swap, load_checkpoint) must refuse; after a fresh capture it agrees with the eager step again."""
+    from oracle import vqvae_oracle as orc
+    from smt_amd import convops
+    from smt_amd.graph import GraphedStep
+    from utils import config as C
+    from utils.commons import get_model, get_optimizer
+    cfg = C.merge(C.load(os.path.join(PKG, "configs/models/vqvae.yaml")),
+                  C.load(os.path.join(PKG, "configs/datasets/synthetic_ljspeech.yaml")),
+                  C.create({"train": {"batch_size": 2, "n_gpus": 1, "ema": True, "grad_clip_norm": None, "seed": 0,
+                                      "log_dir": str(tmp_path), "total_epochs": 1}}))
+    cfg.model.update(C.create(dict(width=64, emb_width=128, l_bins=64, multipliers=[1, 1, 1], compute_dtype="bf16")))
+    cfg.model.loss.linf_topk = 128
+    cfg.model.revival_threshold = 0.0
+    dev = torch.device("cuda", 0)
+    x = orc.synthetic_clip_batch(2, 16384, 5).cuda()
+    lens = torch.tensor([16384, 12288]).cuda()
+    batch = [None, None, None, None, x, lens, None]
+    torch.manual_seed(0)
+    model, ema = get_model(C.create(cfg.to_dict()), dev)
+    opt, sched = get_optimizer(cfg, model)
+    model.train()
+    stale, _ = model.supervised_step(batch)
+    stale["loss"].backward()
+    opt.zero_grad(set_to_none=True)
+
+    def build():
+        return GraphedStep(model, lambda *slots: model.supervised_step(list(slots)), batch,
+                           lambda: opt.zero_grad(set_to_none=True), warmup=0)
+    # `stale["yh"]` is the decoder's output: its grad_fn keeps the whole graph of that iteration alive
+    with pytest.raises(RuntimeError, match="autograd graph of an earlier iteration"):
+        build()
+    del stale
+    graph = build()
+    loss_a = float(graph.replay(*batch)[0]["loss"])
+    opt.step()
+    ema.swap(); ema.swap()                       # validation in train.py: throws the packed copies away (twice)
+    with pytest.raises(RuntimeError, match="invalidated"):
+        graph.replay(*batch)
+    seed = model._drop_seed
+    graph = build()                              # a fresh capture works (its equality with the eager step is the test above)
+    assert model._drop_seed == seed
+    loss_b = float(graph.replay(*batch)[0]["loss"])
+    assert loss_b == loss_b and loss_b != loss_a            # finite, and the optimizer step in between is visible
+
+
 def test_training_on_one_batch_drives_the_loss_down(tmp_path):
     """End-to-end sanity that the optimizer's updates reach every kernel: 60 train steps on one ragged batch (bf16 conv
     stacks, dropout on, AdamW) must cut the training loss by a large factor -- measured: 4193 -> 1930, the spectral term

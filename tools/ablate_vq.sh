@@ -4,9 +4,12 @@
 # Results are NOT valid.  Phase timestamps: build with -DVQ_ABL=16 and run tools/vq_phases.py.
 set -e
 cd "$(dirname "$0")/../speech-masters-thesis_amd/csrc"
+# ablated objects go to build_abl/ and a library of their own: the product build (build/, libsmt_hip.so) is never touched
+make -s && mkdir -p build_abl && cp build/*.o build_abl/
+export SMT_HIP_LIB="$PWD/../smt_amd/libsmt_hip_abl.so"
 for m in ${MASKS:-0 1 2 4 8 15}; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=on -DVQ_ABL=$m -c vq.hip -o build/vq.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../smt_amd/libsmt_hip.so build/*.o
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=on -DVQ_ABL=$m -c vq.hip -o build_abl/vq.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../smt_amd/libsmt_hip_abl.so build_abl/*.o
   echo "== VQ_ABL=$m"
   (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abl$m -o vq -- python3 $OLDPWD/../../tools/bench_vq.py 2 > /tmp/abl$m.log 2>&1; python3 $OLDPWD/../../tools/kstats.py /tmp/abl$m/vq_kernel_stats.csv 12 | grep "search\|candid\|exact\|reduce")
 done

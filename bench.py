@@ -59,8 +59,12 @@ def parse(argv=None):
                         "kernels around them: ~4 %% of the step when every step is instrumented)")
     p.add_argument("--cpu_clip_len", type=int, default=CLIP_LEN // 2,
                    help="clip length of the bounded CPU-baseline sample (half an utterance keeps 3 + 5 steps near 20-30 s)")
+    p.add_argument("--cpu_steps", type=int, default=10, help="timed steps of the CPU-baseline leg (SURVEY 8(d): 3 warm-up + 10)")
     p.add_argument("--no_fp32", action="store_true", help="skip the secondary fp32 (parity path) measurement")
     p.add_argument("--no_graph", action="store_true", help="skip the secondary hipGraph-replay measurement")
+    p.add_argument("--no_ragged", action="store_true", help="skip the secondary ragged-length run (SURVEY 8(d))")
+    p.add_argument("--ragged_steps", type=int, default=6)
+    p.add_argument("--no_micro", action="store_true", help="skip the VQ micro-benchmark and the mel-STFT kernel measurement")
     p.add_argument("--graph_leg", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("--fp32_steps", type=int, default=3)
     return p.parse_args(argv)
@@ -101,7 +105,7 @@ def usable_cpus():
 
 def cpu_baseline(args):
     """The oracle (CPU restatement of the reference path, oracle/vqvae_oracle.py) timed on this box's host cores on
-    a bounded sample, protocol of SURVEY 8(d) / BASELINE.md 3: one thread per usable core, 3 warm-up + 5 timed train
+    a bounded sample, protocol of SURVEY 8(d) / BASELINE.md 3: one thread per usable core, 3 warm-up + 10 timed train
     steps, median.  The sample is ONE clip of --cpu_clip_len samples per step (default half an utterance, so the leg
     stays near 20-30 s); the rate is converted to full-length utterances/s by the sample ratio (the conv stacks, which
     are the step, cost the same per sample at any length)."""
@@ -119,7 +123,7 @@ def cpu_baseline(args):
     for _ in range(3):
         trainer.step(x, lens)
     times = []
-    for _ in range(5):
+    for _ in range(args.cpu_steps):
         t0 = time.perf_counter()
         trainer.step(x, lens)
         times.append(time.perf_counter() - t0)
@@ -128,7 +132,7 @@ def cpu_baseline(args):
     return {"value": frac / med, "unit": "utterances/s", "cores": cores, "threads": threads,
             "logical_cpus_visible": os.cpu_count(), "kind": "port",
             "sample": f"oracle train step (fp32, torch-CPU), batch 1 x {args.cpu_clip_len} samples "
-                      f"({frac:.3f} of a {args.clip_len}-sample utterance), 3 warm-up + 5 timed steps, median "
+                      f"({frac:.3f} of a {args.clip_len}-sample utterance), 3 warm-up + {args.cpu_steps} timed steps, median "
                       f"{med:.2f} s/step (min {min(times):.2f}, max {max(times):.2f}); value = {frac:.3f} / median"}
 
 
@@ -344,6 +348,101 @@ def aux_main(args, device):
     print(json.dumps(out), flush=True)
 
 
+def ragged_lengths(n, seed=0):
+    """SURVEY 8(d) secondary run: clip lengths ~ U[24,064, 222,720] rounded down to a multiple of 512 (the dataset's rule,
+    reference datasets/ljspeech.py:14,82), seeded."""
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randint(24064, 222720 + 1, (n,), generator=g) // 512) * 512
+
+
+def timed_ragged(args, step_fn_factory, rank, device, note):
+    """Secondary measurement: the SAME train step on ragged batches -- lengths U[24,064, 222,720] x 512, seed 0, each batch
+    zero-padded to its own longest clip exactly as the reference's collate does (datasets/ljspeech.py:135-138) -- to show what
+    padding costs.  Four distinct batches are cycled; `padded_fraction` = padded samples / processed samples."""
+    from datasets.synthetic import synth_clip
+    n_batches = 4
+    lens_all = ragged_lengths(n_batches * args.batch, seed=0).view(n_batches, args.batch)
+    pool, real, padded = [], 0, 0
+    for bi in range(n_batches):
+        lens = lens_all[bi]
+        tmax = int(lens.max())
+        clips = torch.zeros(args.batch, tmax)
+        for i in range(args.batch):
+            clips[i, :int(lens[i])] = synth_clip(int(lens[i]), 900000 + (1000 * rank + bi) * 64 + i)
+        pool.append([None, None, None, None, clips.unsqueeze(1).to(device), lens.to(device), None])
+        real += int(lens.sum()); padded += args.batch * tmax
+    step = step_fn_factory(pool)
+    for i in range(2):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.ragged_steps):
+        step(2 + i)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    utt = args.batch * args.ragged_steps / el
+    # fixed-length equivalent: utterances of the headline length carrying the same number of REAL samples per second
+    mean_len = real / (n_batches * args.batch)
+    note(f"ragged run: {utt:.1f} utt/s, padded fraction {1 - real / padded:.3f}")
+    return {"value": utt, "unit": "utterances/s", "ms_per_step": el / args.ragged_steps * 1e3, "steps": args.ragged_steps,
+            "warmup": 2, "mean_len": mean_len, "max_len": int(lens_all.max()), "min_len": int(lens_all.min()),
+            "padded_fraction": 1 - real / padded, "real_samples_per_s": utt * mean_len,
+            "note": "lengths ~ U[24064, 222720] // 512 * 512, torch.Generator seed 0, 4 batches of "
+                    f"{args.batch} cycled, each padded to its own maximum (reference datasets/ljspeech.py:135-138); "
+                    "padded_fraction = 1 - real samples / processed samples"}
+
+
+def vq_micro(device, note):
+    """SURVEY 8(d) VQ micro-benchmark: x ~ N(0,1) [N,128] seed 0, k ~ N(0,1) [K,128] seed 1, K in {256, 1024}, N in
+    {4,544; 36,352}, all-ones mask; smt_vq_forward (search + candidates + exact + reduce, x_d written) timed with HIP events
+    on the launch stream.  Reported against BOTH bounds the survey names: HBM by algorithmic bytes (1,036 B/vector with x_d
+    + the codebook once) and the fp32-FMA roof by 2 N K D FLOP; plus the bf16-MFMA fraction of the 3 x 2 N K D FLOP the
+    filter really issues, and the number of rows that had to be re-scored exactly (fp64 path)."""
+    from smt_amd import vq
+    out = []
+    for k_bins in (256, 1024):
+        for n in (4544, 36352):
+            x = torch.randn(n, 128, generator=torch.Generator().manual_seed(0)).to(device)
+            cb = torch.randn(k_bins, 128, generator=torch.Generator().manual_seed(1)).to(device)
+            prep = vq.prepare(cb)
+            sums = vq.vq_forward_raw(x, cb, None, prep=prep)[3]
+            ms = _timed(lambda: vq.vq_forward_raw(x, cb, None, prep=prep), 50, 5)
+            us = ms * 1e3
+            nbytes = n * (4 * 128 + 8 + 4 + 4 * 128) + 4 * k_bins * 128
+            flops = 2.0 * n * k_bins * 128
+            out.append({"K": k_bins, "N": n, "us": us, "exact_rows": int(sums[3].item()),
+                        "hbm": {"achieved": nbytes / us * 1e-3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / us * 1e-3 / HBM_PEAK_GBS,
+                                "alg_bytes": nbytes},
+                        "f32_fma": {"achieved": flops / us * 1e-6, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": flops / us * 1e-6 / F32_MFMA_PEAK_TFLOPS},
+                        "bf16_mfma": {"achieved": 3 * flops / us * 1e-6, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": 3 * flops / us * 1e-6 / BF16_MFMA_PEAK_TFLOPS}})
+    note("vq micro: " + ", ".join(f"K{r['K']}xN{r['N']} {r['us']:.0f} us" for r in out))
+    return out
+
+
+def melspec_roofline(args, audio, device, note):
+    """The first kernel north_star names: windowed STFT + mel-filterbank contraction + log (reference MelSpectrogram.forward,
+    datasets/transforms.py:48-65; n_fft 1024, hop 256, 80 mels, 22.05 kHz, 0-8 kHz: configs/datasets/ljspeech.yaml) on the
+    headline batch (32 x 145,408 samples), one launch, HIP events on the launch stream.  Algorithmic bytes: 4 B/sample in +
+    80 x 4 / 256 = 1.25 B/sample out = 5.25 B/sample."""
+    from datasets.transforms import MelSpectrogram
+    from smt_amd import spectral
+    mel = MelSpectrogram(n_fft=1024, hop_length=256, win_length=1024, n_mels=80, sample_rate=22050, f_min=0.0, f_max=8000.0).to(device)
+    x = audio.reshape(audio.shape[0], -1).contiguous()
+    out = mel(x)
+    # the kernel alone: MelSpectrogram.forward also asserts the [-1, 1] range (two reductions and a host sync, transforms.py:49)
+    ms = _timed(lambda: spectral.log_mel(x, mel.mel_basis, mel.band, 1024, 256, 1024), 50, 5)
+    us = ms * 1e3
+    nbytes = x.numel() * 4 + out.numel() * 4
+    note(f"melspec: {us:.1f} us = {nbytes / us * 1e-3:.0f} GB/s")
+    return {"kernel": "smt::melspec_kernel (windowed STFT + mel contraction + log, one launch)", "bound": "hbm",
+            "achieved": nbytes / us * 1e-3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / us * 1e-3 / HBM_PEAK_GBS,
+            "avg_us": us, "launches_timed": 50, "alg_bytes_per_launch": nbytes, "bytes_per_sample": nbytes / x.numel(),
+            "frames": int(out.shape[-1]), "traffic": None,
+            "note": f"batch {x.shape[0]} x {x.shape[1]} samples; not on the VQ-VAE train step (SURVEY D1), measured stand-alone"}
+
+
 def launch_or_none(args, argv):
     """`python bench.py --gpus N` with N > 1 outside torchrun: start N rank processes of this script (fresh
     interpreters; this parent makes no HIP call) and return their exit code.  None = run in this process."""
@@ -551,7 +650,7 @@ def main(argv=None):
         n_rows = args.batch * (args.clip_len // 128)
 
         pmc, pmc_source = {}, None
-        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             pmc_path = os.path.join(REPO, "profiles", name)
             if os.path.exists(pmc_path):
                 with open(pmc_path) as f:
@@ -654,6 +753,19 @@ def main(argv=None):
             "kernels": kernels,
         }
         note(f"timed region done: {line['value']:.2f} utt/s, {line['ms_per_step']:.1f} ms/step")
+        for key in ("vq_forward", "vq_ema_accumulate"):        # spread over the timed steps, not only the mean
+            rec = next((k for k in kernels if k["name"] == key), None)
+            if rec is not None and key in extra_rooflines:
+                extra_rooflines[key]["min_us"], extra_rooflines[key]["max_us"] = rec["min_us"], rec["max_us"]
+        if world == 1 and not args.no_micro:
+            line["rooflines_other"]["melspec"] = melspec_roofline(args, pool[0][4], device, note)
+            line["vq_micro"] = vq_micro(device, note)
+        if world == 1 and not args.no_ragged:
+            def factory(rpool):
+                return lambda i: trainlib.train_step(global_step=i, batch=rpool[i % len(rpool)], config=cfg, model=model, ema=ema,
+                                                     optimizer=optimizer, scheduler=scheduler, device=device, rank=rank,
+                                                     grad_sync=grad_sync)
+            line["ragged"] = timed_ragged(args, factory, rank, device, note)
         if world == 1 and not args.no_graph:
             line["hip_graph"] = timed_graph(args, note)
         if world == 1 and not args.no_fp32 and m.get("compute_dtype") == "bf16":

@@ -53,7 +53,8 @@ def summary():
             achieved, peak, unit = nbytes / avg_us * 1e-3, HBM_PEAK_GBS, "GB/s"
         else:
             achieved, peak, unit = flops / avg_us * 1e-6, PEAK_TFLOPS[dtype], "TFLOP/s"
-        out.append({"name": name, "launches": len(recs), "avg_us": avg_us, "total_ms": sum(us) * 1e-3,
+        out.append({"name": name, "launches": len(recs), "avg_us": avg_us, "min_us": min(us), "max_us": max(us),
+                    "total_ms": sum(us) * 1e-3,
                     "bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
                     "alg_bytes": nbytes, "alg_flops": flops,
                     "alt_tflops": flops / avg_us * 1e-6 if flops else None})

@@ -682,7 +682,7 @@ def main(argv=None):
 
         dt = "bf16" if m.get("compute_dtype") == "bf16" else "f32"
         # dominant kernel by time: the weight-stationary implicit-GEMM conv kernel (dilated 128->128 convs, fwd + dgrad)
-        roofline = group({"conv_ws", "conv_ws_pipe"}, "smt::conv_ws_kernel / conv_ws_pipe_kernel (dilated 128->128 convs, forward + data gradient)",
+        roofline = group({"conv_ws", "conv_ws_pipe", "conv_ws2"}, "smt::conv_ws2_kernel / conv_ws_pipe_kernel / conv_ws_kernel (dilated 128->128 convs, forward + data gradient)",
                          "mfma", dt, "conv_ws_kernel")
         if roofline is None:   # fp32 configuration: everything runs on the generic kernel
             roofline = group({"conv_gemm"}, "smt::conv_gemm_kernel", "mfma", dt, "conv_gemm_kernel")

@@ -206,6 +206,14 @@ size_t smt_conv1d_wgrad_workspace_bytes(const smt_conv_desc* desc);
 int smt_conv1d_wgrad(const smt_conv_desc* desc, float* dweight, int64_t stride_out, int64_t stride_in,
                      int64_t stride_tap, const int* tap_map, float* dbias, void* workspace,
                      size_t workspace_bytes, smt_stream_t stream);
+/* Every weight-gradient entry point (smt_conv1d_wgrad, smt_conv1x1_bwd, smt_conv_k1_bwd, smt_conv_gate_bwd) leaves
+ * per-workgroup partial sums in its workspace and then reduces them in a fixed order (bitwise reproducible).  Between
+ * smt_wgrad_reduce_defer(1, .) and smt_wgrad_reduce_defer(0, stream) the calls of this thread only QUEUE that reduction
+ * (up to 16 per launch, job descriptors travel by value in the kernel arguments): each call must then be handed a workspace
+ * of its own that stays untouched until the closing call, which launches the queued reductions on `stream`.  dweight / dbias
+ * are valid once that launch has run.  Replaces autograd's per-layer weight gradients of the reference (the convolutions of
+ * models/vqvae/resnet.py:205-241): one reduction launch per GatedHiFiBlock instead of ten. */
+int smt_wgrad_reduce_defer(int on, smt_stream_t stream);
 /* Name of the kernel smt_conv1d_wgrad runs for this descriptor ("conv_wgrad_shift", "conv_wgrad_dma", "conv_wgrad");
  * no device work. */
 const char* smt_conv1d_wgrad_kernel_name(const smt_conv_desc* desc);

@@ -669,6 +669,41 @@ __global__ __launch_bounds__(DMA_NT) void conv1x1_dma_kernel(ConvArgs p, const _
 //     only that back, so the epilogue operands need neither registers during the tap loop nor a barrier.
 // Measured motivation (tools/ablate_dma.sh): the streaming kernel spends as long waiting for HBM (tile in,
 // tile out) as it does in MFMAs, and with one workgroup per CU the two never overlap.
+// Buffer addressing (raw V#, byte offsets): rows outside [0, valid rows) fall outside num_records and read as zero /
+// are not stored -- the hardware's range check replaces the per-lane bounds tests and zero-page selects, and a per-lane
+// 32-bit offset replaces the 64-bit address arithmetic (both were VALU work serial with the MFMAs: tools/ws_phases.py
+// measured 1,100-2,000 cycles per tile for the issue of ~5 DMA instructions per wave).
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ws_rsrc(const void* base, long long byte_off, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base)) + byte_off, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void ws_dma16(__amdgpu_buffer_rsrc_t rs, unsigned voff, void* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, 0, 0, 0);
+}
+typedef short s16x2v __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2v __attribute__((ext_vector_type(2)));
+// relu on a packed bf16 pair: a negative bf16 is a negative int16 (v_pk_max_i16)
+__device__ __forceinline__ unsigned pk_relu_bf16(unsigned w) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2v, w), s16x2v{0, 0}));
+}
+// 0xFFFF per 16-bit half of h that is >= thr (thr_m1 = thr - 1 in both halves, thr >= 1): saturating subtract, min 1, negate
+__device__ __forceinline__ unsigned pk_keep_mask(unsigned h, unsigned thr_m1) {
+  u16x2v d = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2v, h), __builtin_bit_cast(u16x2v, thr_m1));
+  d = __builtin_elementwise_min(d, u16x2v{1, 1});
+  return __builtin_bit_cast(unsigned, (u16x2v)(u16x2v{0, 0} - d));
+}
+
+#ifndef SMT_WS_STAMP
+#define SMT_WS_STAMP 0   // diagnostic build (tools/ws_phases.sh): per-wave cycle sums of the phases of conv_ws2_kernel
+#endif
+#if SMT_WS_STAMP
+__device__ unsigned long long ws_dbg[256 * 8 * 8];
+#define WS_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define WS_ACC(k, a, b) do { if (lane == 0 && wg < 256) ws_dbg[(wg * 8 + wave) * 8 + (k)] += (b) - (a); } while (0)
+#else
+#define WS_T(var) do {} while (0)
+#define WS_ACC(k, a, b) do {} while (0)
+#endif
 constexpr int WS_AGPR_TAPS = 8;   // taps whose weights are pinned to AccVGPRs (8 x 32 = all 256)
 constexpr int WS_BM = 128, WS_NT = 256, WS_EPI = 128 * 256;   // rows per tile, threads, epilogue-operand tile bytes
 
@@ -729,33 +764,36 @@ __global__ __launch_bounds__(WS_NT) void conv_ws_kernel(ConvArgs p, const __bf16
     b = bb / rs; cls = bb - b * rs;
     t0 = (tile - bb * p.tiles_per_batch) * BM;
   };
+  // buffer addressing (ws_rsrc / ws_dma16): per-lane byte offsets are tile-invariant up to a scalar; rows outside
+  // [0, valid rows) are out of range of the V# and read as zero.  Group g = wave + 4 j covers rows 16 j + 4 wave + lrow,
+  // so the swizzle term (row & 15) does not depend on j.
+  const unsigned pitch_x = (unsigned)p.ldx * rs * 2u;
+  const unsigned voff_a0 = (unsigned)(4 * wave + lrow) * pitch_x + (unsigned)((lch ^ ((4 * wave + lrow) & 15)) << 4);
+  const int ngroups = rows_pad >> 2;
   auto stage_a = [&](int tile, int buf) {
     int b, cls, t0;
     decode(tile, b, cls, t0);
-    const T* xg = reinterpret_cast<const T*>(p.x) + (long long)b * p.x_bs + (long long)cls * p.ldx;
-    const long long ldx = (long long)p.ldx * rs;
     const int len_full = p.lens_in ? min(p.lens_in[b], p.Tin) : p.Tin;
     const int len_in = max(0, (len_full - cls + rs - 1) / rs);
-    const int tin0 = t0 - p.pad;
-    for (int g = wave; g < rows_pad / 4; g += NT / 64) {
-      const int row = 4 * g + lrow;
-      const int tin = tin0 + row;
-      const bool ok = (row < rows_in) && (tin >= 0) && (tin < len_in);
-      const T* src = ok ? xg + (long long)tin * ldx + ((lch ^ (row & 15)) * EPV) : zero_page + lch * EPV;
-      dma16(src, smem + (size_t)buf * buf_bytes + g * 1024);
+    const __amdgpu_buffer_rsrc_t rx = ws_rsrc(p.x, ((long long)b * p.x_bs + (long long)cls * p.ldx) * 2, (unsigned)len_in * pitch_x);
+    unsigned vo = voff_a0 + (unsigned)(t0 - p.pad) * pitch_x;      // rows before the item wrap to huge offsets: zero
+    unsigned char* dst = smem + (size_t)buf * buf_bytes + wave * 1024;
+    for (int g = wave; g < ngroups; g += NT / 64) {
+      ws_dma16(rx, vo, dst);
+      vo += 16u * pitch_x; dst += 4096;
     }
   };
   // this wave's slice of an epilogue operand: one DMA instruction = 16 rows x 64 B; slot c of row n holds the
   // 16-byte chunk c ^ ((n >> 2) & 3) of the slice (keeps the 8-byte fragment reads at <= 2-way bank conflicts)
-  auto stage_epi = [&](const T* base, long long bs, int ld, int b, int cls, int t0, int Tc, unsigned char* dst) {
-    const T* g0 = base + (long long)b * bs + n0 + wave * 32;
+  const unsigned echunk = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+  auto stage_epi = [&](const void* base, long long bs, int ld, int b, int cls, int t0, int Tc, unsigned char* dst) {
+    const unsigned pitch = (unsigned)ld * rs * 2u;
+    const __amdgpu_buffer_rsrc_t re = ws_rsrc(base, ((long long)b * bs + (long long)cls * ld + n0 + wave * 32) * 2, (unsigned)Tc * pitch);
+    unsigned vo = (unsigned)(t0 + (lane >> 2)) * pitch + echunk;
 #pragma unroll
     for (int q = 0; q < BM / 16; ++q) {
-      const int row = 16 * q + (lane >> 2), slot = lane & 3;
-      const int tc = t0 + row;
-      const int chunk = slot ^ ((row >> 2) & 3);
-      const T* src = (tc < Tc) ? g0 + (long long)(cls + (long long)rs * tc) * ld + chunk * EPV : zero_page + slot * EPV;
-      dma16(src, dst + q * 1024);
+      ws_dma16(re, vo, dst + q * 1024);
+      vo += 16u * pitch;
     }
   };
 
@@ -768,11 +806,15 @@ __global__ __launch_bounds__(WS_NT) void conv_ws_kernel(ConvArgs p, const __bf16
     const int Tc = (p.Tout - cls + rs - 1) / rs;
     // tile `tile` is in LDS for every wave (each waited for its own DMAs before its previous epilogue) and
     // every wave is done reading the other buffer
+    WS_T(c0);
     __syncthreads();
+    WS_T(c1);
     if (tile + 1 < tile_end) stage_a(tile + 1, buf ^ 1);
-    if (has_res) stage_epi(reinterpret_cast<const T*>(p.res), p.res_bs, p.ldr, b, cls, t0, Tc, lds_res);
-    if (has_epi_act) stage_epi(reinterpret_cast<const T*>(p.gate_h), p.gh_bs, p.ldgh, b, cls, t0, Tc, lds_act);
+    WS_T(c2);
+    if (has_res) stage_epi(p.res, p.res_bs, p.ldr, b, cls, t0, Tc, lds_res);
+    if (has_epi_act) stage_epi(p.gate_h, p.gh_bs, p.ldgh, b, cls, t0, Tc, lds_act);
 
+    WS_T(c4);
     f32x16 acc[MW];
 #pragma unroll
     for (int i = 0; i < MW; ++i)
@@ -838,26 +880,76 @@ __global__ __launch_bounds__(WS_NT) void conv_ws_kernel(ConvArgs p, const __bf16
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
                  : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
     }
+    WS_T(c5);
     // next tile + this tile's epilogue operands have landed (issued a whole tap loop ago); older stores retired
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WS_T(c6);
     if (ABL & 32) {   // ablation: no epilogue
       asm volatile("" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
       continue;
     }
 
-    // ---- epilogue straight from the accumulators; same arithmetic as the other kernels: bf16(acc + bias) first
-    T* yg = has_y ? reinterpret_cast<T*>(p.y) + (long long)b * p.y_bs : nullptr;
-    T* ug = has_act_out ? reinterpret_cast<T*>(p.y_act) + (long long)b * p.ya_bs : nullptr;
+    // ---- epilogue straight from the accumulators; same arithmetic as the other kernels: bf16(acc + bias) first.
+    // Stores go through range-checked buffer descriptors (rows >= Tc are dropped by the hardware, 32-bit offsets).
     const int len_out = p.lens_out ? p.lens_out[b] : 0x7fffffff;
+    const unsigned pitch_y = (unsigned)p.ldy * rs * 2u, pitch_u = (unsigned)p.ldya * rs * 2u;
+    const __amdgpu_buffer_rsrc_t ry = ws_rsrc(has_y ? p.y : p.x, has_y ? ((long long)b * p.y_bs + (long long)cls * p.ldy + n0 + wave * 32) * 2 : 0,
+                                              has_y ? (unsigned)Tc * pitch_y : 0u);
+    const __amdgpu_buffer_rsrc_t ru = ws_rsrc(has_act_out ? p.y_act : p.x,
+                                              has_act_out ? ((long long)b * p.ya_bs + (long long)cls * p.ldya + n0 + wave * 32) * 2 : 0,
+                                              has_act_out ? (unsigned)Tc * pitch_u : 0u);
+    if constexpr (MODE == 2) {
+      // dx = y * scale * [u != 0] * row mask + residual, written for few VALU instructions (tools/ws_phases.py: at one wave
+      // per SIMD the epilogue and the DMA issue are serial with the tap loop).  The eight LDS reads of a row block are
+      // issued together, so their latency is paid once per row block.  (Tried and dropped in round 3: loading the two
+      // operands straight into registers in the store layout after touching their lines before the tap loop -- the 4-byte
+      // touches, 64 lines per instruction, slowed the tap loop by 20 %: 826 vs 775 us at 9 taps.)
+#pragma unroll
+      for (int i = 0; i < MW; ++i) {
+        const int row = 32 * i + r;
+        const int tc = t0 + row;
+        const float srow = (cls + rs * tc >= len_out) ? 0.f : p.drop_scale;     // row mask and 1 / (1 - p) in one factor
+        const int swz = (row >> 2) & 3;
+        uint2 uv[4], rv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int eoff = row * 64 + ((g ^ swz) << 4) + 8 * hh;
+          uv[g] = *reinterpret_cast<const uint2*>(lds_act + eoff);
+          rv[g] = *reinterpret_cast<const uint2*>(lds_res + eoff);
+        }
+        unsigned yp[8];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const unsigned uvp[2] = {uv[g].x, uv[g].y}, rvp[2] = {rv[g].x, rv[g].y};
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const unsigned ypk = pack_bf16x2(acc[i][4 * g + 2 * j] + bval[4 * g + 2 * j], acc[i][4 * g + 2 * j + 1] + bval[4 * g + 2 * j + 1]);
+            const float o0 = __builtin_bit_cast(float, ypk << 16), o1 = __builtin_bit_cast(float, ypk & 0xffff0000u);
+            const float v0 = (uvp[j] & 0x7fffu) ? o0 * srow : 0.f, v1 = (uvp[j] & 0x7fff0000u) ? o1 * srow : 0.f;
+            yp[2 * g + j] = pack_bf16x2(v0 + __builtin_bit_cast(float, rvp[j] << 16), v1 + __builtin_bit_cast(float, rvp[j] & 0xffff0000u));
+          }
+        }
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            auto sw = __builtin_amdgcn_permlane32_swap(yp[4 * h2 + d], yp[4 * h2 + 2 + d], false, false);
+            yp[4 * h2 + d] = sw[0]; yp[4 * h2 + 2 + d] = sw[1];
+          }
+        const unsigned vo = (unsigned)tc * pitch_y + (unsigned)hh * 16u;
+        __builtin_amdgcn_raw_buffer_store_b128(i32x4v{(int)yp[0], (int)yp[1], (int)yp[2], (int)yp[3]}, ry, (int)vo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(i32x4v{(int)yp[4], (int)yp[5], (int)yp[6], (int)yp[7]}, ry, (int)(vo + 32u), 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < MW; ++i) {
       const int row = 32 * i + r;
       const int tc = t0 + row;
-      const bool ok = tc < Tc;
       const int ty = cls + rs * tc;                          // actual output row
       const float keep_row = (ty >= len_out) ? 0.f : 1.f;
       const int swz = (row >> 2) & 3;
       unsigned yp[8], up[8];
+      {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float o[4];
@@ -893,6 +985,7 @@ __global__ __launch_bounds__(WS_NT) void conv_ws_kernel(ConvArgs p, const __bf16
           }
         }
       }
+      }
       // lanes r and r + 32 hold channels {0-3, 8-11, 16-19, 24-27} and {4-7, 12-15, 20-23, 28-31} of the same
       // row: swap so that lane r owns 0-7 | 16-23 and lane r + 32 owns 8-15 | 24-31 (16-byte pieces)
       auto pair_up = [&](unsigned* v) {
@@ -904,25 +997,22 @@ __global__ __launch_bounds__(WS_NT) void conv_ws_kernel(ConvArgs p, const __bf16
             v[4 * h2 + d] = sw[0]; v[4 * h2 + 2 + d] = sw[1];
           }
       };
-      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-      const int scol = n0 + wave * 32 + 8 * hh;
       if (has_y) {
         pair_up(yp);
-        if (ok) {
-          T* dst = yg + (long long)ty * p.ldy + scol;
-          *reinterpret_cast<u32x4*>(dst) = u32x4{yp[0], yp[1], yp[2], yp[3]};
-          *reinterpret_cast<u32x4*>(dst + 16) = u32x4{yp[4], yp[5], yp[6], yp[7]};
-        }
+        const unsigned vo = (unsigned)tc * pitch_y + (unsigned)hh * 16u;
+        __builtin_amdgcn_raw_buffer_store_b128(i32x4v{(int)yp[0], (int)yp[1], (int)yp[2], (int)yp[3]}, ry, (int)vo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(i32x4v{(int)yp[4], (int)yp[5], (int)yp[6], (int)yp[7]}, ry, (int)(vo + 32u), 0, 0);
       }
       if (has_act_out) {
         pair_up(up);
-        if (ok) {
-          T* dst = ug + (long long)ty * p.ldya + scol;
-          *reinterpret_cast<u32x4*>(dst) = u32x4{up[0], up[1], up[2], up[3]};
-          *reinterpret_cast<u32x4*>(dst + 16) = u32x4{up[4], up[5], up[6], up[7]};
-        }
+        const unsigned vo = (unsigned)tc * pitch_u + (unsigned)hh * 16u;
+        __builtin_amdgcn_raw_buffer_store_b128(i32x4v{(int)up[0], (int)up[1], (int)up[2], (int)up[3]}, ru, (int)vo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(i32x4v{(int)up[4], (int)up[5], (int)up[6], (int)up[7]}, ru, (int)(vo + 32u), 0, 0);
       }
     }
+    }
+    WS_T(c7);
+    WS_ACC(0, c0, c1); WS_ACC(1, c1, c2); WS_ACC(3, c2, c4); WS_ACC(4, c4, c5); WS_ACC(5, c5, c6); WS_ACC(6, c6, c7); WS_ACC(7, c0, c0 + 1);
   }
 }
 
@@ -1000,26 +1090,28 @@ __global__ __launch_bounds__(WS_NT) void conv_ws_pipe_kernel(ConvArgs p, const _
     b = bb / rs; cls = bb - b * rs;
     t0 = (tile - bb * p.tiles_per_batch) * BM;
   };
+  // buffer addressing as in conv_ws_kernel: one per-lane offset, a scalar per tile, out-of-range rows read as zero
+  const unsigned pitch_x = (unsigned)p.ldx * rs * 2u;
+  const unsigned voff_a0 = (unsigned)(4 * wave + lrow) * pitch_x + (unsigned)((lch ^ ((4 * wave + lrow) & 15)) << 4);
+  const int ngroups = rows_pad >> 2;
   auto stage_a = [&](int tile, int buf) {
     int b, cls, t0;
     decode(tile, b, cls, t0);
-    const T* xg = reinterpret_cast<const T*>(p.x) + (long long)b * p.x_bs + (long long)cls * p.ldx;
-    const long long ldx = (long long)p.ldx * rs;
     const int len_full = p.lens_in ? min(p.lens_in[b], p.Tin) : p.Tin;
     const int len_in = max(0, (len_full - cls + rs - 1) / rs);
-    const int tin0 = t0 - p.pad;
-    for (int g = wave; g < rows_pad / 4; g += NT / 64) {
-      const int row = 4 * g + lrow;
-      const int tin = tin0 + row;
-      const bool ok = (row < rows_in) && (tin >= 0) && (tin < len_in);
-      const T* src = ok ? xg + (long long)tin * ldx + ((lch ^ (row & 15)) * EPV) : zero_page + lch * EPV;
-      dma16(src, smem + (size_t)buf * buf_bytes + g * 1024);
+    const __amdgpu_buffer_rsrc_t rx = ws_rsrc(p.x, ((long long)b * p.x_bs + (long long)cls * p.ldx) * 2, (unsigned)len_in * pitch_x);
+    unsigned vo = voff_a0 + (unsigned)(t0 - p.pad) * pitch_x;
+    unsigned char* dst = smem + (size_t)buf * buf_bytes + wave * 1024;
+    for (int g = wave; g < ngroups; g += NT / 64) {
+      ws_dma16(rx, vo, dst);
+      vo += 16u * pitch_x; dst += 4096;
     }
   };
 
   // ---- state of the tile whose epilogue is pending
   unsigned pc[MW][8];                 // bf16 pairs of (acc + bias): pc[i][2g + h] = elements 4g + 2h, 4g + 2h + 1
   int p_b = 0, p_cls = 0, p_t0 = 0, p_Tc = 0, p_len = 0;
+  __amdgpu_buffer_rsrc_t p_ru = ws_rsrc(p.y_act, 0, 0);      // output rows of the pending item (set at the hand-over)
   // ---- scratch of the micro-steps (live across MFMAs)
   float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f, u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f, keepf = 1.f;
   unsigned h0 = 0, h1 = 0, rh = 0, up[8];
@@ -1070,11 +1162,10 @@ __global__ __launch_bounds__(WS_NT) void conv_ws_pipe_kernel(ConvArgs p, const _
           up[4 * h2 + d] = sw[0]; up[4 * h2 + 2 + d] = sw[1];
         }
     } else {
-      if (ty >= 0) {
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        T* dst = reinterpret_cast<T*>(p.y_act) + (long long)p_b * p.ya_bs + (long long)ty * p.ldya + n0 + wave * 32 + 8 * hh;
-        *reinterpret_cast<u32x4*>(dst) = u32x4{up[0], up[1], up[2], up[3]};
-        *reinterpret_cast<u32x4*>(dst + 16) = u32x4{up[4], up[5], up[6], up[7]};
+      if (ty >= 0) {      // 32-bit offset from the pending item's base (a scalar); the V# covers the whole output tensor
+        const unsigned vo = (unsigned)ty * ((unsigned)p.ldya * 2u) + (unsigned)hh * 16u;
+        __builtin_amdgcn_raw_buffer_store_b128(i32x4v{(int)up[0], (int)up[1], (int)up[2], (int)up[3]}, p_ru, (int)vo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(i32x4v{(int)up[4], (int)up[5], (int)up[6], (int)up[7]}, p_ru, (int)(vo + 32u), 0, 0);
       }
     }
   };
@@ -1152,10 +1243,282 @@ __global__ __launch_bounds__(WS_NT) void conv_ws_pipe_kernel(ConvArgs p, const _
 #pragma unroll
       for (int e = 0; e < 16; e += 2) pc[i][e >> 1] = pack_bf16x2(acc[i][e] + bval[e], acc[i][e + 1] + bval[e + 1]);
     p_b = b; p_cls = cls; p_t0 = t0;
+    p_ru = ws_rsrc(p.y_act, ((long long)b * p.ya_bs + n0 + wave * 32) * 2, (unsigned)p.Ty * ((unsigned)p.ldya * 2u));
     p_Tc = (p.Tout - cls + rs - 1) / rs;
     p_len = p.lens_out ? p.lens_out[b] : 0x7fffffff;
   }
   static_for<0, PH_TILE>(epi);                          // epilogue of the last tile
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight-stationary kernel with TWO waves per SIMD (3 and 5 taps: 96 / 160 weight registers per wave leave room for a
+// second wave in the 512-entry register file).  conv_ws_kernel runs one wave per SIMD, and a wave issues in order: its
+// epilogue (VALU), its LDS-DMA issue and its barrier wait are all serial with its own MFMAs -- at 3 taps the matrix pipe
+// is busy 30 % of the time (profiles/r02_pmc_mfma.txt).  Here a 512-thread workgroup splits the 128-row tile into two
+// 64-row halves: waves w and w + 4 share a SIMD, own the SAME 32 output channels (both hold that weight slice) and
+// different halves of the rows.  The two run the same program with one barrier per tile, but STAGGERED
+// (MI355X_MICROARCH.md, "Two waves per SIMD", item 9): waves 0-3 multiply tile n and then write it out, waves 4-7 first
+// write out tile n-1 (its sums stay in the accumulators across the barrier) and then multiply tile n -- so on every SIMD
+// one wave's MFMA segment always sits beside its partner's epilogue segment (matrix beside VALU / memory, the pairing
+// that nets).  Same arithmetic per output as conv_ws_kernel: bit-identical results.
+// MODE 1 = activated output only (K2 forward), 2 = y with activation-gradient mask and residual (K2 data gradient).
+constexpr int WS2_NT = 512;
+// conv_ws2_kernel is dispatched up to this tap count.  Five taps compile (4 taps in AccVGPRs + 1 in VGPRs) but spill 7-24
+// registers to scratch in the epilogue and run slower than the one-wave kernels (r03: 638 vs 490 us at the top level).
+constexpr int WS2_MAX_TAPS = 3;
+
+template <int NTAPS, int MODE>
+__global__ __launch_bounds__(WS2_NT) void conv_ws2_kernel(ConvArgs p, const __bf16* __restrict__ zero_page,
+                                                          int tiles_per_wg, int buf_bytes) {
+  typedef __bf16 T;
+  constexpr int BM = WS_BM, BN = 128, KC = 128, NT = WS2_NT, MW = 2, ROWB = KC * 2;
+  constexpr int NSTEP = NTAPS * (KC / 16), NG = 5;          // NG: 4-row staging groups per wave (<= 160 rows per tile)
+  static_assert(MODE == 1 || MODE == 2, "two epilogues");
+  // Register budget at two waves per SIMD: 256 per lane, which the compiler splits 128 AccVGPRs / 128 VGPRs as soon as a
+  // kernel names AccVGPRs (telling it to take 160 through an "a159" clobber leaves the VGPR side at 128 and the kernel
+  // at one wave per SIMD): four taps (128 registers) are pinned there, a fifth lives in VGPRs, and what else is live
+  // (32 accumulators, 24 fragment registers, offsets) has to fit beside it -- the bias values come from LDS for that.
+  constexpr int AGPR_TAPS = NTAPS < 4 ? NTAPS : 4;
+  static_assert(NTAPS <= 5, "weights of more than five taps do not fit two waves per SIMD");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cw = wave & 3, rhalf = wave >> 2;              // column group (32 output channels), row half = phase
+  const int r = lane & 31, hh = lane >> 5;
+  const int n0 = blockIdx.y * BN;
+  const int rs = p.rs;
+
+  const int ntiles = p.tiles_per_batch * p.B * rs;
+  const int nwg = gridDim.x;
+  const int wg = (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3);
+  const int tile_begin = wg * tiles_per_wg;
+  const int tile_end = min(ntiles, tile_begin + tiles_per_wg);
+  if (tile_begin >= tile_end) return;
+
+  // fp32 bias of the 128 output channels, then (MODE 2) the epilogue-operand slices: per wave [64 rows][64 B] (its 32
+  // channels of its row half), 16-byte chunks swizzled
+  float* lds_bias = reinterpret_cast<float*>(smem + 2 * (size_t)buf_bytes);
+  unsigned char* lds_res = smem + 2 * (size_t)buf_bytes + 1024 + wave * (WS_EPI / 8);
+  unsigned char* lds_act = lds_res + WS_EPI;
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  if (tid < BN) lds_bias[tid] = p.bias ? p.bias[n0 + tid] : 0.f;       // visible after the first barrier of the tile loop
+
+  bf16x8 wfrag[NTAPS][KC / 16];
+  {
+    const int co = n0 + cw * 32 + r;
+#pragma unroll
+    for (int s = 0; s < NTAPS; ++s) {
+      const unsigned char* wrow = reinterpret_cast<const unsigned char*>(p.w) + ((size_t)s * p.Cout + co) * ROWB;
+#pragma unroll
+      for (int kk = 0; kk < KC / 16; ++kk)
+        wfrag[s][kk] = *reinterpret_cast<const bf16x8*>(wrow + (((2 * kk + hh) ^ (co & 15)) << 4));
+    }
+  }
+  // accumulator element 4g + k of a lane = output channel col0 + 8g + k (this lane's row: 64 rhalf + 32 i + r)
+  const int col0 = n0 + cw * 32 + 4 * hh;
+  // dropout (MODE 1): hash input of the pair (row, col0 + 8g + 2j ..+1) = rowh + kc[g] + j C, with
+  // rowh = ((b Ty + ty) site_width / 2) C (mod 2^32) = scalar part + lane part, kc[g] = (column / 2) C + key
+  const unsigned HC = 0x9E3779B1u;
+  const unsigned swh = (unsigned)p.site_width >> 1;
+  unsigned kc[4];
+  unsigned rowh_lane = 0;
+  const unsigned thr_m1 = (p.drop_thresh16 - 1u) * 0x00010001u;
+  if (MODE == 1) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = col0 + 8 * g;
+      const int site = col / p.site_width;
+      kc[g] = ((unsigned)(col - site * p.site_width) >> 1) * HC + site_key(p, site);
+    }
+    rowh_lane = HC * swh * (unsigned)(rs * r);
+  }
+  const int rows_in = BM + (NTAPS - 1) * p.dil;
+  const int ngroups = (rows_in + 3) >> 2;
+
+  // ---- byte pitches of the class-domain rows and the tile-invariant per-lane offsets
+  const unsigned pitch_x = (unsigned)p.ldx * rs * 2u;
+  unsigned voff_a[NG];
+#pragma unroll
+  for (int j = 0; j < NG; ++j) {
+    const int row = 4 * (wave + 8 * j) + (lane >> 4);
+    voff_a[j] = (unsigned)row * pitch_x + (unsigned)(((lane & 15) ^ (row & 15)) << 4);
+  }
+  const unsigned pitch_o = (MODE == 2 ? (unsigned)p.ldy : (unsigned)p.ldya) * rs * 2u;    // output rows
+  const unsigned voff_o = (unsigned)(64 * rhalf + r) * pitch_o + (unsigned)hh * 16u;      // row block i: + 32 i pitch_o
+  const unsigned pitch_r = (unsigned)p.ldr * rs * 2u, pitch_g = (unsigned)p.ldgh * rs * 2u;
+  const int elr = 64 * rhalf + (lane >> 2);                                                 // + 16 q: staged row of the slices
+  const unsigned echunk = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);                // chunk (lane & 3) ^ ((row >> 2) & 3)
+
+  auto decode = [&](int tile, int& b, int& cls, int& t0) {
+    const int bb = tile / p.tiles_per_batch;
+    b = bb / rs; cls = bb - b * rs;
+    t0 = (tile - bb * p.tiles_per_batch) * BM;
+  };
+  auto stage_a = [&](int tile, int buf) {
+    int b, cls, t0;
+    decode(tile, b, cls, t0);
+    const int len_full = p.lens_in ? min(p.lens_in[b], p.Tin) : p.Tin;
+    const int len_in = max(0, (len_full - cls + rs - 1) / rs);
+    const __amdgpu_buffer_rsrc_t rx = ws_rsrc(p.x, ((long long)b * p.x_bs + (long long)cls * p.ldx) * 2, (unsigned)len_in * pitch_x);
+    const unsigned s0 = (unsigned)(t0 - p.pad) * pitch_x;       // rows before the item wrap to huge offsets: out of range, zero
+    unsigned char* dst = smem + (size_t)buf * buf_bytes + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < NG; ++j)
+      if (wave + 8 * j < ngroups) ws_dma16(rx, voff_a[j] + s0, dst + j * 8192);
+  };
+  // this wave's slice of an epilogue operand: one DMA instruction = 16 rows x 64 B; slot c of local row n holds the
+  // 16-byte chunk c ^ ((n >> 2) & 3) of the slice
+  auto stage_epi = [&](const void* base, long long bs, int ld, unsigned pitch, int b, int cls, int t0, int Tc, unsigned char* dst) {
+    const __amdgpu_buffer_rsrc_t re = ws_rsrc(base, ((long long)b * bs + (long long)cls * ld + n0 + cw * 32) * 2, (unsigned)Tc * pitch);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ws_dma16(re, (unsigned)(t0 + elr + 16 * q) * pitch + echunk, dst + q * 1024);
+  };
+
+  f32x16 acc[MW];
+  // ---- epilogue of one tile half straight from the accumulators (the arithmetic of conv_ws_kernel, written for few VALU
+  //      instructions: the epilogue, not the matrix pipe, bounds this kernel at 3 taps)
+  auto epilogue = [&](int b, int cls, int t0, int Tc) {
+    const int len_out = p.lens_out ? p.lens_out[b] : 0x7fffffff;
+    const __amdgpu_buffer_rsrc_t ry =
+        MODE == 2 ? ws_rsrc(p.y, ((long long)b * p.y_bs + (long long)cls * p.ldy + n0 + cw * 32) * 2, (unsigned)Tc * pitch_o)
+                  : ws_rsrc(p.y_act, ((long long)b * p.ya_bs + (long long)cls * p.ldya + n0 + cw * 32) * 2, (unsigned)Tc * pitch_o);
+    const unsigned so = (unsigned)t0 * pitch_o;
+    const unsigned rowh_s = MODE == 1 ? HC * swh * ((unsigned)b * (unsigned)p.Ty + (unsigned)cls + (unsigned)rs * (unsigned)(t0 + 64 * rhalf)) : 0u;
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+      const int lr = 32 * i + r;                                // row inside this wave's half
+      const int ty = cls + rs * (t0 + 64 * rhalf + lr);         // actual output row
+      const float srow = (ty >= len_out) ? 0.f : p.drop_scale;  // row mask and 1 / (1 - p) in one factor
+      const int swz = (lr >> 2) & 3;
+      unsigned yp[8];
+      const unsigned rowh = rowh_s + rowh_lane + HC * swh * (unsigned)(rs * 32 * i);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(lds_bias + cw * 32 + 4 * hh + 8 * g);
+        unsigned uvp[2] = {0, 0}, rvp[2] = {0, 0};
+        if (MODE == 2) {
+          const int eoff = lr * 64 + ((g ^ swz) << 4) + 8 * hh;
+          const uint2 uv = *reinterpret_cast<const uint2*>(lds_act + eoff);
+          const uint2 rv = *reinterpret_cast<const uint2*>(lds_res + eoff);
+          uvp[0] = uv.x; uvp[1] = uv.y; rvp[0] = rv.x; rvp[1] = rv.y;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          // y = bf16(acc + bias), two elements per conversion
+          const unsigned ypk = pack_bf16x2(acc[i][4 * g + 2 * j] + bv[2 * j], acc[i][4 * g + 2 * j + 1] + bv[2 * j + 1]);
+          const float o0 = __builtin_bit_cast(float, ypk << 16), o1 = __builtin_bit_cast(float, ypk & 0xffff0000u);
+          if (MODE == 1) {
+            // u = relu(dropout(y)): scale (row mask folded in), round, relu + keep mask on the packed pair
+            unsigned w = pk_relu_bf16(pack_bf16x2(o0 * srow, o1 * srow));
+            if (p.drop_thresh16) w &= pk_keep_mask(fmix32(rowh + kc[g] + (unsigned)j * HC), thr_m1);
+            yp[2 * g + j] = w;
+          } else {
+            // dx = y * scale * [u != 0] * row mask + residual
+            const unsigned u2 = uvp[j], r2 = rvp[j];
+            const float v0 = (u2 & 0x7fffu) ? o0 * srow : 0.f, v1 = (u2 & 0x7fff0000u) ? o1 * srow : 0.f;
+            yp[2 * g + j] = pack_bf16x2(v0 + __builtin_bit_cast(float, r2 << 16), v1 + __builtin_bit_cast(float, r2 & 0xffff0000u));
+          }
+        }
+      }
+      // lanes r and r + 32 hold channels {0-3, 8-11, 16-19, 24-27} and {4-7, 12-15, 20-23, 28-31} of the same
+      // row: swap so that lane r owns 0-7 | 16-23 and lane r + 32 owns 8-15 | 24-31 (16-byte pieces)
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          auto sw = __builtin_amdgcn_permlane32_swap(yp[4 * h2 + d], yp[4 * h2 + 2 + d], false, false);
+          yp[4 * h2 + d] = sw[0]; yp[4 * h2 + 2 + d] = sw[1];
+        }
+      const unsigned vo = voff_o + so + (unsigned)(32 * i) * pitch_o;    // rows >= Tc are out of range: dropped by the hardware
+      __builtin_amdgcn_raw_buffer_store_b128(i32x4v{(int)yp[0], (int)yp[1], (int)yp[2], (int)yp[3]}, ry, (int)vo, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(i32x4v{(int)yp[4], (int)yp[5], (int)yp[6], (int)yp[7]}, ry, (int)(vo + 32u), 0, 0);
+    }
+  };
+
+  stage_a(tile_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int pb = 0, pcls = 0, pt0 = 0, pTc = 0;        // the tile whose sums waves 4-7 still hold
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    const int buf = (tile - tile_begin) & 1;
+    int b, cls, t0;
+    decode(tile, b, cls, t0);
+    const int Tc = (p.Tout - cls + rs - 1) / rs;
+    // tile `tile` is in LDS for every wave (each waited for its own DMAs before arriving here) and every wave is done
+    // reading the other buffer
+    WS_T(c0);
+    __syncthreads();
+    WS_T(c1);
+    if (tile + 1 < tile_end) stage_a(tile + 1, buf ^ 1);
+    WS_T(c2);
+    if (rhalf == 1 && tile > tile_begin) epilogue(pb, pcls, pt0, pTc);
+    WS_T(c3);
+    if (MODE == 2) {                         // this wave's slices are free: its previous epilogue is done
+      stage_epi(p.res, p.res_bs, p.ldr, pitch_r, b, cls, t0, Tc, lds_res);
+      stage_epi(p.gate_h, p.gh_bs, p.ldgh, pitch_g, b, cls, t0, Tc, lds_act);
+    }
+    WS_T(c4);
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    // MFMA pipeline over the NTAPS x 8 k-steps: the fragments of step q + 2 are requested before the MFMAs of step q
+    // (two MFMAs = 64 cycles per step would not cover the LDS latency with a distance of one)
+    const unsigned abase = lds_base + (unsigned)buf * (unsigned)buf_bytes + (unsigned)(64 * rhalf) * ROWB;
+    unsigned tap_base[NTAPS];
+#pragma unroll
+    for (int s = 0; s < NTAPS; ++s) {
+      const int ar = r + s * p.dil;                 // rows ar + 32 i (+ 64 rhalf) share the swizzle term (ar & 15)
+      tap_base[s] = abase + ar * ROWB + ((hh ^ (ar & 15)) << 4);
+    }
+    auto frag_addr = [&](int q) -> unsigned { return tap_base[q / (KC / 16)] ^ (32u * (q % (KC / 16))); };
+    bf16x8 afr[3][MW];
+#pragma unroll
+    for (int q0 = 0; q0 < 2; ++q0) {
+      const unsigned ap = frag_addr(q0);
+#pragma unroll
+      for (int i = 0; i < MW; ++i)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(afr[q0][i]) : "v"(ap), "n"(i * 32 * ROWB));
+    }
+    static_for<0, NSTEP>([&](auto Q) {
+      constexpr int q = decltype(Q)::value;
+      if constexpr (q + 2 < NSTEP) {
+        const unsigned ap = frag_addr(q + 2);
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(afr[(q + 2) % 3][i]) : "v"(ap), "n"(i * 32 * ROWB));
+        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+      } else if constexpr (q + 1 < NSTEP) {
+        asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      // (clang's implicit capture in a generic lambda misses a variable that is only named in asm operands)
+      constexpr int i0 = q - q, i1 = i0 + 1;
+      (void)&acc; (void)&wfrag;       // odr-use outside asm: forces the capture
+      // first use of an accumulator: VALU write -> MFMA SrcC needs wait states the compiler cannot see through asm
+      if constexpr (q == 0) asm volatile("s_nop 4" : "+v"(acc[i0]), "+v"(acc[i1]));
+      if constexpr (q / (KC / 16) < AGPR_TAPS) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i0]) : "a"(wfrag[q / (KC / 16)][q % (KC / 16)]), "v"(afr[q % 3][i0]));
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i1]) : "a"(wfrag[q / (KC / 16)][q % (KC / 16)]), "v"(afr[q % 3][i1]));
+      } else {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i0]) : "v"(wfrag[q / (KC / 16)][q % (KC / 16)]), "v"(afr[q % 3][i0]));
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i1]) : "v"(wfrag[q / (KC / 16)][q % (KC / 16)]), "v"(afr[q % 3][i1]));
+      }
+    });
+    static_assert(MW == 2, "two accumulators per wave");
+    // the hazard recogniser does not see MFMAs inside asm: let the last ones drain before VALU reads acc
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
+    WS_T(c5);
+    // next tile + this tile's epilogue operands have landed; older stores retired
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WS_T(c6);
+    if (rhalf == 0) epilogue(b, cls, t0, Tc);
+    WS_T(c7);
+    WS_ACC(0, c0, c1); WS_ACC(1, c1, c2); WS_ACC(2, c2, c3); WS_ACC(3, c3, c4); WS_ACC(4, c4, c5); WS_ACC(5, c5, c6);
+    WS_ACC(6, c6, c7); WS_ACC(7, c0, c0 + 1);
+    pb = b; pcls = cls; pt0 = t0; pTc = Tc;
+  }
+  if (rhalf == 1) epilogue(pb, pcls, pt0, pTc);
 }
 
 template <int NTAPS, int MODE>
@@ -1170,6 +1533,19 @@ static void launch_ws(const ConvArgs& p, const void* zero_page, dim3 grid, size_
                       hipStream_t stream) {
   const bool y = p.y != nullptr, ao = p.act_out != 0, res = p.res != nullptr, ea = p.epi_act != 0;
   static const bool no_pipe = getenv("SMT_CONV_NO_PIPE") != nullptr;
+  if constexpr (NTAPS <= WS2_MAX_TAPS) {   // two waves per SIMD, staggered (conv_ws2_kernel)
+    static const bool no_ws2 = getenv("SMT_CONV_NO_WS2") != nullptr;
+    if (!no_ws2 && !y && ao && !res && !ea) {
+      (void)hipFuncSetAttribute((const void*)conv_ws2_kernel<NTAPS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      conv_ws2_kernel<NTAPS, 1><<<grid, WS2_NT, 2 * (size_t)buf_bytes + 1024, stream>>>(p, (const __bf16*)zero_page, tpw, buf_bytes);
+      return;
+    }
+    if (!no_ws2 && y && !ao && res && ea) {
+      (void)hipFuncSetAttribute((const void*)conv_ws2_kernel<NTAPS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      conv_ws2_kernel<NTAPS, 2><<<grid, WS2_NT, lds + 1024, stream>>>(p, (const __bf16*)zero_page, tpw, buf_bytes);
+      return;
+    }
+  }
   if (!y && ao && !res && !ea && !no_pipe) {
     (void)hipFuncSetAttribute((const void*)conv_ws_pipe_kernel<NTAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     conv_ws_pipe_kernel<NTAPS><<<grid, WS_NT, lds, stream>>>(p, (const __bf16*)zero_page, tpw, buf_bytes);
@@ -1717,6 +2093,14 @@ static ConvKernelKind pick_kernel(const smt_conv_desc* d, const ConvArgs& p0) {
   return pl.ws ? K_WS : K_DMA;
 }
 
+#if SMT_WS_STAMP
+extern "C" int smt_ws_debug_dump(unsigned long long* host, int n, int reset) {
+  int rc = (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ws_dbg), sizeof(unsigned long long) * n);
+  if (reset) { static unsigned long long z[256 * 8 * 8]; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(ws_dbg), z, sizeof(z)); }
+  return rc;
+}
+#endif
+
 extern "C" int smt_conv1d_ntc(const smt_conv_desc* d, smt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SMT_CHECK_ARG(d && d->x && d->w && (d->y || d->y_act), "smt_conv1d_ntc: null pointer");
@@ -1765,8 +2149,11 @@ extern "C" const char* smt_conv1d_kernel_name(const smt_conv_desc* d) {
     case K_1X1: return "conv1x1_dma";
     case K_FOLD: return "conv1x1_fold";
     case K_K1ACT: return "conv_k1act";
-    case K_WS:   // same rule as launch_ws: the activated-output-only epilogue has the pipelined variant
-      return (!d->y && d->act_out && !d->res && !d->act_grad && !getenv("SMT_CONV_NO_PIPE")) ? "conv_ws_pipe" : "conv_ws";
+    case K_WS: {  // same rule as launch_ws: two waves per SIMD for <= 5 taps; else the pipelined variant for the activated-output epilogue
+      const bool fwd = !d->y && d->act_out && !d->res && !d->act_grad, dgrad = d->y && !d->act_out && d->res && d->act_grad;
+      if (d->taps <= WS2_MAX_TAPS && (fwd || dgrad) && !getenv("SMT_CONV_NO_WS2")) return "conv_ws2";
+      return (fwd && !getenv("SMT_CONV_NO_PIPE")) ? "conv_ws_pipe" : "conv_ws";
+    }
     case K_DMA: return "conv_gemm_dma";
     default: return "conv_gemm";
   }

@@ -572,51 +572,91 @@ static void launch_shift(const ShiftArgs& a, const void* zero_page, dim3 grid, h
   conv_wgrad_shift_kernel<NTAPS><<<grid, 512, 2 * SH_STAGE, stream>>>(a, (const __bf16*)zero_page);
 }
 
-struct WreduceArgs {
+// ---- fixed-order reduction of the partial slabs -------------------------------------------------------------------
+// One job = one weight (+ bias) gradient: slab[chunk][blk][plane][64 co][cib ci] -> dw (torch layout), db.  Jobs travel BY
+// VALUE in the kernel arguments (no table upload, capturable in a hipGraph); up to WR_MAXJ jobs share one launch, so a
+// GatedHiFi block's ten weight gradients cost one reduce launch instead of ten (smt_wgrad_reduce_defer / _flush).
+struct WreduceJob {
   const float* slab; float* dw; float* db;
-  int n_chunks, nblk, nblk_ci, planes, taps, Cin, Cout, with_bias, cib;
-  int bias_cols;   // the bias plane holds partial sums in columns 0, 32, .. 32 (bias_cols - 1): add them
-  long long so, si, sj; int jmap[16];
+  long long so, si, sj;
+  int n_chunks, nblk, nblk_ci, planes, taps, Cin, Cout, cib, bias_cols;
+  int block0;                      // first workgroup of this job inside the launch
+  int wblocks;                     // workgroups of the weight part (the bias part follows)
+  signed char jmap[16];
 };
+constexpr int WR_MAXJ = 16;
+struct WreduceBatch { int n_jobs, total_blocks; WreduceJob job[WR_MAXJ]; };
 
-// 32 outputs x 8 chunk slices per workgroup: thread (o, s) sums chunks s, s+8, ... in index order, the
-// eight slice sums are then added in slice order -- a fixed summation tree, so the result is
-// bitwise reproducible, with 8x the memory parallelism of one thread per output.
-__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(WreduceArgs p) {
-  __shared__ float part[8][32];
-  const long long total = (long long)p.planes * p.Cout * p.Cin;
+// Weight part: a workgroup owns 32 float4 outputs (128 consecutive ci of one (plane, co) row... up to row ends) x 8
+// chunk slices: thread (o, s) sums chunks s, s+8, ... in index order (four independent 16-byte loads in flight), the
+// eight slice sums are then added in slice order -- the same fixed summation tree as the first version of this kernel
+// (one float per thread, one load in flight: latency-bound, 17 us per call whatever the size), so the results are
+// bit-identical to it and bitwise reproducible.  Bias part: one thread per output channel and slice, columns 0, 32, ..
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(WreduceBatch bt) {
+  __shared__ f32x4 part[8][32];
+  int j = 0;
+#pragma unroll 1
+  for (int k = 1; k < bt.n_jobs; ++k)
+    if ((int)blockIdx.x >= bt.job[k].block0) j = k;
+  const WreduceJob& p = bt.job[j];
+  const int lb = blockIdx.x - p.block0;
   const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const long long e = (long long)blockIdx.x * 32 + o;
-  float s = 0.f;
-  bool live = e < total;
-  int ci = 0, co = 0, plane = 0;
-  if (live) {
-    ci = (int)(e % p.Cin); co = (int)((e / p.Cin) % p.Cout); plane = (int)(e / ((long long)p.Cin * p.Cout));
-    if (plane == p.taps && ci != 0) live = false;  // bias plane: every ci column holds db[co]; take column 0
-  }
-  if (live) {
-    const int blk = (co / 64) * p.nblk_ci + (ci / p.cib);
-    const size_t blk_elems = (size_t)p.planes * 64 * p.cib;
-    const float* src = p.slab + (size_t)blk * blk_elems + ((size_t)plane * 64 + (co % 64)) * p.cib + (ci % p.cib);
-    if (plane == p.taps && p.bias_cols > 1) {
+  const size_t blk_elems = (size_t)p.planes * 64 * p.cib;
+  const size_t cstride = (size_t)p.nblk * blk_elems;
+  if (lb < p.wblocks) {
+    const int cin4 = p.Cin >> 2;
+    const long long total4 = (long long)p.taps * p.Cout * cin4;
+    const long long e4 = (long long)lb * 32 + o;
+    const bool live = e4 < total4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int ci = 0, co = 0, plane = 0;
+    if (live) {
+      ci = (int)(e4 % cin4) * 4; co = (int)((e4 / cin4) % p.Cout); plane = (int)(e4 / ((long long)cin4 * p.Cout));
+      const int blk = (co / 64) * p.nblk_ci + (ci / p.cib);
+      const float* src = p.slab + (size_t)blk * blk_elems + ((size_t)plane * 64 + (co % 64)) * p.cib + (ci % p.cib);
+      int c = sl;
+      for (; c + 24 < p.n_chunks; c += 32) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + (size_t)c * cstride);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + (size_t)(c + 8) * cstride);
+        const f32x4 v2 = *reinterpret_cast<const f32x4*>(src + (size_t)(c + 16) * cstride);
+        const f32x4 v3 = *reinterpret_cast<const f32x4*>(src + (size_t)(c + 24) * cstride);
+        s += v0; s += v1; s += v2; s += v3;
+      }
+      for (; c < p.n_chunks; c += 8) s += *reinterpret_cast<const f32x4*>(src + (size_t)c * cstride);
+    }
+    part[sl][o] = s;
+    __syncthreads();
+    if (sl == 0 && live) {
+      f32x4 t = part[0][o];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) t += part[k][o];
+      float* dst = p.dw + co * p.so + ci * p.si + p.jmap[plane] * p.sj;
+      dst[0] = t[0]; dst[p.si] = t[1]; dst[2 * p.si] = t[2]; dst[3 * p.si] = t[3];
+    }
+  } else {
+    float* part1 = reinterpret_cast<float*>(&part[0][0]);      // [8][32]
+    const int co = (lb - p.wblocks) * 32 + o;
+    const bool live = co < p.Cout && p.db != nullptr;
+    float s = 0.f;
+    if (live) {
+      // bias plane: column 0 of every ci block holds db[co] (or partial sums in columns 0, 32, .. of the first block)
+      const int blk = (co / 64) * p.nblk_ci;
+      const float* src = p.slab + (size_t)blk * blk_elems + ((size_t)p.taps * 64 + (co % 64)) * p.cib;
       for (int c = sl; c < p.n_chunks; c += 8) {
-        const float* q = src + (size_t)c * p.nblk * blk_elems;
+        const float* q = src + (size_t)c * cstride;
         float part_sum = q[0];
         for (int k = 1; k < p.bias_cols; ++k) part_sum += q[32 * k];
         s += part_sum;
       }
-    } else {
-      for (int c = sl; c < p.n_chunks; c += 8) s += src[(size_t)c * p.nblk * blk_elems];
     }
-  }
-  part[sl][o] = s;
-  __syncthreads();
-  if (sl == 0 && live) {
-    float t = part[0][o];
+    part1[sl * 32 + o] = s;
+    __syncthreads();
+    if (sl == 0 && live) {
+      float t = part1[o];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) t += part[k][o];
-    if (plane < p.taps) p.dw[co * p.so + ci * p.si + p.jmap[plane] * p.sj] = t;
-    else if (p.db) p.db[co] = t;
+      for (int k = 1; k < 8; ++k) t += part1[k * 32 + o];
+      p.db[co] = t;
+    }
   }
 }
 
@@ -656,25 +696,53 @@ static void wgrad_plan(const smt_conv_desc* d, int* rows_per_chunk, int* chunks_
   *planes = d->taps + 1;
 }
 
+static thread_local bool g_reduce_defer = false;
+static thread_local WreduceBatch g_reduce_batch = {0, 0, {}};
+
+static int reduce_flush(hipStream_t stream) {
+  if (g_reduce_batch.n_jobs > 0 && g_reduce_batch.total_blocks > 0) {
+    conv_wgrad_reduce_kernel<<<(unsigned)g_reduce_batch.total_blocks, 256, 0, stream>>>(g_reduce_batch);
+    g_reduce_batch.n_jobs = 0; g_reduce_batch.total_blocks = 0;
+    SMT_CHECK_LAUNCH("conv_wgrad_reduce");
+  }
+  g_reduce_batch.n_jobs = 0; g_reduce_batch.total_blocks = 0;
+  return 0;
+}
+
 int launch_wgrad_reduce(const float* slab, float* dw, float* db, int n_chunks, int nblk_co, int nblk_ci, int taps,
                         int c_in, int c_out, int cib, long long so, long long si, long long sj, const int* jmap,
                         hipStream_t stream, int bias_cols) {
-  WreduceArgs r;
+  SMT_CHECK_ARG(c_in % 4 == 0 && cib % 4 == 0 && taps <= 16, "conv_wgrad_reduce: c_in and the ci block must be multiples of 4");
+  if (g_reduce_batch.n_jobs == WR_MAXJ) {
+    int rc = reduce_flush(stream);
+    if (rc) return rc;
+  }
+  WreduceJob& r = g_reduce_batch.job[g_reduce_batch.n_jobs];
   r.bias_cols = bias_cols;
   r.slab = slab; r.dw = dw; r.db = db;
   r.n_chunks = n_chunks; r.nblk = nblk_co * nblk_ci; r.nblk_ci = nblk_ci; r.planes = taps + 1; r.taps = taps;
-  r.Cin = c_in; r.Cout = c_out; r.with_bias = db ? 1 : 0; r.cib = cib;
+  r.Cin = c_in; r.Cout = c_out; r.cib = cib;
   r.so = so; r.si = si; r.sj = sj;
-  for (int t = 0; t < taps; ++t) r.jmap[t] = jmap[t];
-  const long long total = (long long)r.planes * c_out * c_in;
-  conv_wgrad_reduce_kernel<<<(unsigned)((total + 31) / 32), 256, 0, stream>>>(r);
-  SMT_CHECK_LAUNCH("conv_wgrad_reduce");
-  return 0;
+  for (int t = 0; t < 16; ++t) r.jmap[t] = (signed char)(t < taps ? jmap[t] : 0);
+  const long long total4 = (long long)taps * c_out * (c_in / 4);
+  r.wblocks = (int)((total4 + 31) / 32);
+  r.block0 = g_reduce_batch.total_blocks;
+  g_reduce_batch.total_blocks += r.wblocks + (db ? (c_out + 31) / 32 : 0);
+  g_reduce_batch.n_jobs += 1;
+  return g_reduce_defer ? 0 : reduce_flush(stream);
 }
 
 }  // namespace smt
 
 using namespace smt;
+
+extern "C" int smt_wgrad_reduce_defer(int on, smt_stream_t stream_) {
+  // on = 1: the weight-gradient calls that follow on this thread (smt_conv1d_wgrad, smt_conv1x1_bwd, smt_conv_k1_bwd,
+  // smt_conv_gate_bwd) queue their slab reductions instead of launching them; every call must then be given a workspace
+  // of its own, which has to stay untouched until the flush.  on = 0: launch what is queued (one launch per 16 jobs).
+  g_reduce_defer = on != 0;
+  return on ? 0 : reduce_flush((hipStream_t)stream_);
+}
 
 static size_t wgrad_group_ws(const smt_conv_desc* d) {
   int rpc, cpb, nco, nci, planes;
@@ -698,11 +766,13 @@ extern "C" size_t smt_conv1d_wgrad_workspace_bytes(const smt_conv_desc* d) {
   ShiftPlan pl;
   if (wgrad_shift_plan(d, &pl))
     best = (size_t)pl.n_chunks * pl.nblk_co * pl.nblk_ci * (d->taps + 1) * 64 * 128 * sizeof(float);
+  // tap groups get consecutive regions (their reductions may be deferred: smt_wgrad_reduce_defer)
+  size_t groups = 0;
   for (int j0 = 0; j0 < d->taps; j0 += WG_GROUP) {
     smt_conv_desc g = wgrad_group_desc(d, j0, std::min(WG_GROUP, d->taps - j0));
-    best = std::max(best, wgrad_group_ws(&g));
+    groups += align_up(wgrad_group_ws(&g), 256);
   }
-  return best;
+  return std::max(best, groups);
 }
 
 template <typename T, int CIB, bool STRIDED>
@@ -830,11 +900,15 @@ extern "C" int smt_conv1d_wgrad(const smt_conv_desc* d, float* dweight, int64_t 
     return launch_wgrad_reduce((const float*)workspace, dweight, dbias, pl.n_chunks, pl.nblk_co, pl.nblk_ci, d->taps,
                                d->c_in, d->c_out, 128, stride_out, stride_in, stride_tap, tap_map, stream, 4);
   }
+  SMT_CHECK_ARG(workspace_bytes >= smt_conv1d_wgrad_workspace_bytes(d), "smt_conv1d_wgrad: workspace too small");
+  size_t off = 0;
   for (int j0 = 0; j0 < d->taps; j0 += WG_GROUP) {
     smt_conv_desc g = wgrad_group_desc(d, j0, std::min(WG_GROUP, d->taps - j0));
+    const size_t need = align_up(wgrad_group_ws(&g), 256);
     int rc = wgrad_group(&g, dweight, stride_out, stride_in, stride_tap, tap_map + j0, j0 == 0 ? dbias : nullptr,
-                         workspace, workspace_bytes, stream);
+                         (char*)workspace + off, need, stream);
     if (rc) return rc;
+    off += need;
   }
   return 0;
 }

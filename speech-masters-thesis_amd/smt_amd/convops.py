@@ -313,6 +313,21 @@ def _cat_bias(biases):
     return _pack_parts(parts, torch.float32, (1, total, 1))
 
 
+@contextlib.contextmanager
+def reduce_batch(device):
+    """The weight-gradient calls inside the block queue their slab reductions; ONE launch (per 16 jobs) reduces them all when
+    the block ends (smt_wgrad_reduce_defer).  A GatedHiFi block's backward has ten of them: 172 -> ~30 reduce launches per
+    train step.  Every call gets a workspace region of its own from ``native.workspace.arena``."""
+    lib = N.lib()
+    with N.workspace.arena(device):
+        N.check(lib.smt_wgrad_reduce_defer(1, N.stream_ptr()), "smt_wgrad_reduce_defer")
+        try:
+            yield
+        finally:
+            with profiler.region("conv_wgrad_reduce", bound="hbm"):
+                N.check(lib.smt_wgrad_reduce_defer(0, N.stream_ptr()), "smt_wgrad_reduce_defer")
+
+
 _K3GATE = not bool(int(__import__("os").environ.get("SMT_NO_K3GATE", "0")))   # A/B switch for tests and profiles
 
 
@@ -875,13 +890,18 @@ class _GatedHiFi(torch.autograd.Function):
         x, lens32, u1, u2, z, g, *params = ctx.saved_tensors
         geometry, scale, has_lens = ctx.cfg
         lens32 = lens32 if has_lens else None
+        dout = dout.contiguous()
+        with reduce_batch(x.device):      # the block's ten weight gradients: one slab-reduction launch at the end
+            return _GatedHiFi._backward(x, lens32, u1, u2, z, g, params, geometry, scale, dout)
+
+    @staticmethod
+    def _backward(x, lens32, u1, u2, z, g, params, geometry, scale, dout):
         depth = len(geometry)
         b, t, w = x.shape
         c2 = 2 * w
         dt, dev = x.dtype, x.device
         br = [params[6 * d:6 * d + 6] for d in range(depth)]
         wg, bg = params[6 * depth], params[6 * depth + 1]
-        dout = dout.contiguous()
         grads = [None] * len(params)
 
         def f32(shape):

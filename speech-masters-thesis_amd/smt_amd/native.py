@@ -1,4 +1,5 @@
 """ctypes loader for libsmt_hip.so -- the C ABI declared in include/smt_hip.h."""
+import contextlib
 import ctypes
 import os
 import threading
@@ -41,6 +42,7 @@ _SIGNATURES = {
     "smt_conv1d_wgrad_workspace_bytes": (c_size, [c_ptr]),
     "smt_conv1d_wgrad_kernel_name": (ctypes.c_char_p, [c_ptr]),
     "smt_conv1d_wgrad": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "smt_wgrad_reduce_defer": (c_int, [c_int, c_ptr]),
     "smt_conv1x1_bwd_workspace_bytes": (c_size, [c_ptr]),
     "smt_conv1x1_bwd": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_size, c_ptr]),
     "smt_conv_gate_bwd_workspace_bytes": (c_size, [c_int, c_int]),
@@ -143,12 +145,43 @@ def stream_ptr():
 
 
 class Workspace:
-    """Grow-only per-device scratch buffer handed to the kernels (the library never allocates)."""
+    """Grow-only per-device scratch buffer handed to the kernels (the library never allocates).
+
+    Inside ``with workspace.arena(device):`` every ``get`` returns a region of its OWN (256-byte aligned slices of one
+    buffer) that stays untouched until the block ends -- what the deferred slab reductions need (smt_wgrad_reduce_defer)."""
 
     def __init__(self):
         self._buf = {}
+        self._arena = None          # (key, [chunks], offset) while an arena is open
+        self._arena_buf = {}        # key -> buffer kept between arenas (sized for the largest one seen)
+
+    @contextlib.contextmanager
+    def arena(self, device):
+        key = (device.type, device.index)
+        assert self._arena is None, "workspace arenas do not nest"
+        first = self._arena_buf.get(key)
+        self._arena = [key, [first] if first is not None else [], 0, 0]     # key, chunks, offset in the last chunk, total bytes
+        try:
+            yield self
+        finally:
+            _, chunks, _, total = self._arena
+            self._arena = None
+            if len(chunks) > 1 or first is None:      # outgrown: one buffer of the full size for the next time
+                self._arena_buf[key] = torch.empty(max(int(total * 1.25), 1 << 20), dtype=torch.uint8, device=device)
+
+    def _arena_get(self, nbytes, device):
+        key, chunks, off, total = self._arena
+        assert key == (device.type, device.index)
+        need = (int(nbytes) + 255) // 256 * 256
+        if not chunks or off + need > chunks[-1].numel():
+            chunks.append(torch.empty(max(need, 64 << 20), dtype=torch.uint8, device=device))
+            off = 0
+        self._arena[2], self._arena[3] = off + need, total + need
+        return chunks[-1][off:off + need]
 
     def get(self, nbytes, device):
+        if self._arena is not None:
+            return self._arena_get(nbytes, device)
         key = (device.type, device.index)
         buf = self._buf.get(key)
         if buf is None or buf.numel() < nbytes:

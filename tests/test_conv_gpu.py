@@ -314,7 +314,8 @@ def test_weight_stationary_conv_kernel_matches_generic_kernel(k, dil, epi):
         C._launch(d, "t")
         torch.cuda.synchronize()
         outs.append((y, u))
-    assert names == ["conv_gemm", "conv_ws_pipe" if epi == "actout-only" else "conv_ws"]
+    two_waves = k <= 3 and epi in ("actout-only", "res+actgrad")          # conv_ws2_kernel: two staggered waves per SIMD
+    assert names == ["conv_gemm", "conv_ws2" if two_waves else ("conv_ws_pipe" if epi == "actout-only" else "conv_ws")]
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert (outs[0][1] if epi == "actout-only" else outs[0][0]).float().abs().sum() > 0
 

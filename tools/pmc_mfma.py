@@ -15,7 +15,7 @@ import json
 import sys
 
 GROUPS = [
-    ("conv_ws", ["conv_ws_kernel", "conv_ws_pipe_kernel"]),
+    ("conv_ws", ["conv_ws_kernel", "conv_ws_pipe_kernel", "conv_ws2_kernel"]),
     ("conv_wgrad_shift", ["conv_wgrad_shift_kernel"]),
     ("conv_wgrad_other", ["conv_wgrad_kernel", "conv_wgrad_dma_kernel"]),
     ("conv_gemm_dma", ["conv_gemm_dma_kernel"]),

@@ -10,7 +10,7 @@ stores.  Writes <out_prefix>.txt and <out_prefix>.json (bench.py reads the .json
 import csv, json, sys, collections
 
 GROUPS = [  # (key, substrings of the kernel name)
-    ("conv_ws_kernel", ["conv_ws_kernel", "conv_ws_pipe_kernel"]),
+    ("conv_ws_kernel", ["conv_ws_kernel", "conv_ws_pipe_kernel", "conv_ws2_kernel"]),
     ("conv_gemm_dma_kernel", ["conv_gemm_dma_kernel"]),
     ("conv1x1_dma_kernel", ["conv1x1_dma_kernel"]),
     ("conv1x1_fold_kernel", ["conv1x1_fold_kernel"]),

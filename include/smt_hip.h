@@ -401,6 +401,77 @@ int smt_lm_ce_fwd(const float* logits, const int64_t* target, float* row_out, fl
 int smt_lm_ce_bwd(const float* logits, const int64_t* target, const float* lse, const float* coef, float* dlogits,
                   int64_t rows, int vocab, smt_stream_t stream);
 
+/* ------------------------------------------------------- GlowTTS ---- */
+/* SURVEY 8(f4) / BASELINE.json configs[4]: the pieces of the reference's GlowTTS (models/glow_tts/glow_tts.py:59-130,
+ * modules.py:134-236, submodules.py:88-512) that are not convolutions; fp32, channels-last rows [batch, t, channels] with
+ * prefix row masks (lens[batch], NULL = no mask).  Row reductions are two-stage in a fixed order (reproducible).
+ * Workspaces for the column reductions: smt_glow_reduce_workspace_bytes(rows, columns). */
+size_t smt_glow_reduce_workspace_bytes(int64_t rows, int cols);
+/* ActNorm (submodules.py:237-253): z = (bias + exp(logs) x) mask; reverse: (x - bias) exp(-logs) mask.  bwd: dx (may be NULL),
+ * dlogs[c] = sum dz x exp(logs) mask, dbias[c] = sum dz mask; workspace columns = 2 * channels. */
+int smt_glow_actnorm_fwd(const float* x, const float* logs, const float* bias, const int* lens, float* z, int batch, int t,
+                         int channels, int reverse, smt_stream_t stream);
+int smt_glow_actnorm_bwd(const float* x, const float* dz, const float* logs, const int* lens, float* dx, float* dlogs,
+                         float* dbias, int batch, int t, int channels, void* workspace, size_t workspace_bytes,
+                         smt_stream_t stream);
+/* InvConvNear (submodules.py:292-323), n_split = 4: the 4 x 4 weight mixes the channel quadruples (h C/2 + 2 j + k);
+ * transpose = 1 applies weight^T (the data gradient).  wgrad: dweight[s'][s] = sum dz[s'] x[s] over rows and groups
+ * (workspace columns = 16). */
+int smt_glow_invconv(const float* x, const float* weight, const int* lens, float* z, int batch, int t, int channels,
+                     int transpose, smt_stream_t stream);
+int smt_glow_invconv_wgrad(const float* x, const float* dz, const int* lens, float* dweight, int batch, int t, int channels,
+                           void* workspace, size_t workspace_bytes, smt_stream_t stream);
+/* WN gate (submodules.py:88-95 fused_add_tanh_sigmoid_multiply after the in_layer's dropout, :213-220):
+ * acts[r, c] = tanh(d(a[r, c])) sigmoid(d(a[r, hidden + c])), d = counter dropout over the linear index of a [rows, 2 hidden]. */
+int smt_glow_gate_fwd(const float* a, float* acts, int64_t rows, int hidden, uint32_t drop_key, const uint32_t* drop_key_dev,
+                      uint32_t drop_thresh16, float drop_scale, smt_stream_t stream);
+int smt_glow_gate_bwd(const float* a, const float* dacts, float* da, int64_t rows, int hidden, uint32_t drop_key,
+                      const uint32_t* drop_key_dev, uint32_t drop_thresh16, float drop_scale, smt_stream_t stream);
+/* Plain dropout over the linear element index: y[i] = x[i] keep(i) (DurationPredictor, submodules.py:629-633). */
+int smt_glow_dropout(const float* x, float* y, int64_t n, uint32_t drop_key, const uint32_t* drop_key_dev, uint32_t drop_thresh16,
+                     float drop_scale, smt_stream_t stream);
+/* Affine coupling (submodules.py:383-405): out = (m | logs) from the `end` convolution, x = (x0 | x1):
+ * z = (x0 | (m + exp(logs) x1) mask), logdet[b] = sum logs mask (NULL: not wanted; workspace >= batch * ceil(t / 64) floats);
+ * reverse: z1 = (x1 - m) exp(-logs) mask.  bwd: dout = (dm | dlogs), dx = (dz0 | dz1 exp(logs) mask). */
+int smt_glow_coupling_fwd(const float* out, const float* x, const int* lens, float* z, float* logdet, int batch, int t,
+                          int channels, int sigmoid_scale, int reverse, void* workspace, size_t workspace_bytes,
+                          smt_stream_t stream);
+int smt_glow_coupling_bwd(const float* out, const float* x, const float* dz, const float* dlogdet, const int* lens,
+                          float* dout, float* dx, int batch, int t, int channels, int sigmoid_scale, smt_stream_t stream);
+/* Self-attention with relative-position keys and values (AttentionBlock.attention, submodules.py:463-512; window W, the
+ * embeddings [2 W + 1, head_dim] shared by the heads): q, k, v, ctx [batch, t, heads * head_dim]; scores of padded queries /
+ * keys are FILLED with -1e4 like the reference (a fully padded row is uniform); probs [batch, heads, t, t] = the softmax,
+ * kept for the backward; dropout on the probabilities (index = linear index of probs). */
+int smt_glow_attention_fwd(const float* q, const float* k, const float* v, const float* emb_rel_k, const float* emb_rel_v,
+                           const int* lens, float* ctx, float* probs, int batch, int t, int heads, int head_dim, int window,
+                           uint32_t drop_key, const uint32_t* drop_key_dev, uint32_t drop_thresh16, float drop_scale,
+                           smt_stream_t stream);
+size_t smt_glow_attention_bwd_workspace_bytes(int batch, int t, int heads, int head_dim, int window);
+int smt_glow_attention_bwd(const float* q, const float* k, const float* v, const float* emb_rel_k, const float* emb_rel_v,
+                           const float* probs, const float* dctx, float* dq, float* dk, float* dv, float* demb_rel_k,
+                           float* demb_rel_v, int batch, int t, int heads, int head_dim, int window, uint32_t drop_key,
+                           const uint32_t* drop_key_dev, uint32_t drop_thresh16, float drop_scale, void* workspace,
+                           size_t workspace_bytes, smt_stream_t stream);
+/* Prior log-likelihood of every (token, frame) pair (glow_tts.py:87-95), the input of smt_maximum_path:
+ * x_m, x_logs [batch, t_x, dim] (x_logs NULL = zeros), z [batch, t_y, dim] -> logp [batch, t_x, t_y]. */
+int smt_glow_prior_logp(const float* x_m, const float* x_logs, const float* z, float* logp, int batch, int t_x, int t_y,
+                        int dim, smt_stream_t stream);
+/* Alignment path [batch, t_x, t_y] (0/1) -> idx [batch, t_y] (token of each frame, -1 = none), durations [batch, t_x];
+ * gather: z[b, j, :] = x[b, idx[b, j], :] (glow_tts.py:100-101, the matmul with the path); scatter = its adjoint. */
+int smt_glow_align_index(const float* path, int* idx, float* durations, int batch, int t_x, int t_y, smt_stream_t stream);
+int smt_glow_align_gather(const float* x, const int* idx, float* z, int batch, int t_x, int t_y, int dim, smt_stream_t stream);
+int smt_glow_align_scatter(const float* dz, const int* idx, float* dx, int batch, int t_x, int t_y, int dim, smt_stream_t stream);
+/* MLE loss pieces (glow_tts.py:115-119): sums[0] = sum z_logs, sums[1] = sum exp(-2 z_logs) (z - z_m)^2 over n elements
+ * (z_logs NULL = zeros); bwd with the DEVICE scalar coef: dz = coef exp(-2 zl)(z - zm), dz_m = -dz, dz_logs = coef (1 - ...). */
+size_t smt_glow_mle_workspace_bytes(int64_t n);
+int smt_glow_mle_sums(const float* z, const float* z_m, const float* z_logs, int64_t n, float* sums, void* workspace,
+                      size_t workspace_bytes, smt_stream_t stream);
+int smt_glow_mle_bwd(const float* z, const float* z_m, const float* z_logs, const float* coef, int64_t n, float* dz, float* dz_m,
+                     float* dz_logs, smt_stream_t stream);
+/* Duration loss (glow_tts.py:99, 120): diff[b, t] = (logw - log(1e-8 + durations)) mask, sum[0] = sum diff^2. */
+int smt_glow_length_loss(const float* logw, const float* durations, const int* lens, int batch, int t_x, float* diff, float* sum,
+                         smt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -718,7 +718,7 @@ __global__ __launch_bounds__(WS_NT) void conv_ws_kernel(ConvArgs p, const __bf16
   const bool has_res = MODE == 0 ? (p.res != nullptr) : (MODE == 2);
   const bool has_epi_act = MODE == 0 ? (p.epi_act != 0) : (MODE == 2);
   typedef __bf16 T;
-  constexpr int EPV = 8, BM = WS_BM, BN = 128, KC = 128, NT = WS_NT, MW = BM / 32, ROWB = KC * 2;
+  constexpr int BM = WS_BM, BN = 128, KC = 128, NT = WS_NT, MW = BM / 32, ROWB = KC * 2;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;

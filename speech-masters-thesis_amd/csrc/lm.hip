@@ -425,10 +425,10 @@ __global__ __launch_bounds__(256) void lm_add_ln_bwd_kernel(const float* __restr
 }
 #define LM_LN_DISPATCH(dim, CALL)                                                       \
   switch ((dim) / 64) {                                                                 \
-    case 1: CALL(1); break;  case 2: CALL(2); break;  case 4: CALL(4); break;           \
-    case 8: CALL(8); break;  case 12: CALL(12); break; case 16: CALL(16); break;        \
-    case 32: CALL(32); break;                                                           \
-    default: SMT_CHECK_ARG(false, "add_ln: dim %d not built (64 x {1,2,4,8,12,16,32})", (int)(dim)); \
+    case 1: CALL(1); break;  case 2: CALL(2); break;  case 3: CALL(3); break;           \
+    case 4: CALL(4); break;  case 8: CALL(8); break;  case 12: CALL(12); break;         \
+    case 16: CALL(16); break; case 32: CALL(32); break;                                 \
+    default: SMT_CHECK_ARG(false, "add_ln: dim %d not built (64 x {1,2,3,4,8,12,16,32})", (int)(dim)); \
   }
 // fixed-order column sums of part [n][width] -> out [width]: a workgroup takes 64 columns, its four waves a quarter of
 // the rows each; a wave keeps eight loads in flight (row r goes to accumulator r % 8) and the partial sums are combined

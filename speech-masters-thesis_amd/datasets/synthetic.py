@@ -53,3 +53,34 @@ class SyntheticLJSpeech(Dataset):
         return None, None, None, None, audio, audio.shape[-1], None
 
     collate = staticmethod(LJSpeech.collate)
+
+
+class SyntheticTTS(Dataset):
+    """Token ids + log-mel-like frames with LJSpeech-like proportions behind the reference's dataset contract, for the
+    token-to-spectrogram models (GlowTTS): item = (token [Tx] int64, Tx, spect [n_mels, Ty] fp32, Ty, None, None, None)."""
+
+    def __init__(self, config, split):
+        super().__init__()
+        ds = config.dataset
+        self.n = int(ds.get("num_clips", 256)) if split == "train" else 10
+        self.offset = 0 if split == "val" else 10
+        self.max_tokens = int(ds.get("max_tokens", 160))
+        self.fpt = int(ds.get("frames_per_token", 5))
+        self.n_vocab = int(ds.get("n_vocab", 148)) + int(bool(ds.get("intersperse_blanks", False)))
+        self.n_mels = int(ds.get("n_mels", 80))
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, index):
+        g = torch.Generator().manual_seed(50_000 + self.offset + index)
+        tx = int(torch.randint(max(2, self.max_tokens // 2), self.max_tokens + 1, (1,), generator=g))
+        ty = tx * self.fpt + int(torch.randint(0, 2 * self.fpt, (1,), generator=g))
+        token = torch.randint(1, self.n_vocab, (tx,), generator=g)
+        # frames that depend on the token under them (so that an alignment exists to be found) + noise, log-mel range
+        owner = torch.div(torch.arange(ty) * tx, ty, rounding_mode="floor").clamp(max=tx - 1)
+        basis = torch.randn(self.n_vocab, self.n_mels, generator=torch.Generator().manual_seed(7))
+        spect = (basis[token[owner]] * 1.5 - 4.0 + 0.5 * torch.randn(ty, self.n_mels, generator=g)).t().contiguous()
+        return token, tx, spect, ty, None, None, None
+
+    collate = staticmethod(LJSpeech.collate)

@@ -235,13 +235,12 @@ _register_step_post_hook(mark_packed_weights_dirty)
 
 
 def invalidate_packed_weights():
-    """Forget every packed operand copy (``load_checkpoint`` and ``EMA.swap`` call it; a training forward does not need it).
-    A captured hipGraph holds raw pointers into the copies: smt_amd/graph.py keeps the captured entries alive and checks
-    ``pack_epoch()`` before every replay."""
-    _pack_cache.entries.clear()
-    _pack_cache.order.clear()
-    _pack_cache.table = None
-    _pack_cache.epoch += 1
+    """The parameters were written behind torch's back (``p.data.copy_`` as in the reference's ``EMA.swap``, models/ema.py:
+    60-66; ``load_checkpoint``): every packed copy is refreshed at its next use.  The copies themselves -- keyed by the
+    parameters' storage, which such writes do not move, and holding the parameters strongly -- stay where they are, so a
+    captured hipGraph that points at them (smt_amd/graph.py) stays valid; only an overflow of the cache (MAX_ENTRIES)
+    throws them away, which ``pack_epoch()`` reports."""
+    mark_packed_weights_dirty()
 
 
 def pack_epoch():

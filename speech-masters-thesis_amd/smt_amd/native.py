@@ -94,6 +94,29 @@ _SIGNATURES = {
     "smt_lm_bias_relu_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_u32, c_ptr, c_u32, c_f32, c_ptr, c_size, c_ptr]),
     "smt_lm_ce_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr]),
     "smt_lm_ce_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr]),
+    "smt_glow_reduce_workspace_bytes": (c_size, [c_i64, c_int]),
+    "smt_glow_actnorm_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "smt_glow_actnorm_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_size, c_ptr]),
+    "smt_glow_invconv": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "smt_glow_invconv_wgrad": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_size, c_ptr]),
+    "smt_glow_gate_fwd": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_u32, c_ptr, c_u32, c_f32, c_ptr]),
+    "smt_glow_gate_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_u32, c_ptr, c_u32, c_f32, c_ptr]),
+    "smt_glow_dropout": (c_int, [c_ptr, c_ptr, c_i64, c_u32, c_ptr, c_u32, c_f32, c_ptr]),
+    "smt_glow_coupling_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr, c_size, c_ptr]),
+    "smt_glow_coupling_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "smt_glow_attention_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int,
+                                       c_u32, c_ptr, c_u32, c_f32, c_ptr]),
+    "smt_glow_attention_bwd_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),
+    "smt_glow_attention_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int,
+                                       c_int, c_int, c_int, c_u32, c_ptr, c_u32, c_f32, c_ptr, c_size, c_ptr]),
+    "smt_glow_prior_logp": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "smt_glow_align_index": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr]),
+    "smt_glow_align_gather": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "smt_glow_align_scatter": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "smt_glow_mle_workspace_bytes": (c_size, [c_i64]),
+    "smt_glow_mle_sums": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_size, c_ptr]),
+    "smt_glow_mle_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "smt_glow_length_loss": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr]),
 }
 
 

@@ -87,7 +87,10 @@ def get_optimizer(config, model):
     if not sched:
         scheduler = S.DummyLR(optimizer)
     elif sched.name == "noam":
-        scheduler = S.NoamLR(optimizer, dim_model=config.model.d_model, warmup_steps=sched.warmup_steps)
+        # the reference reads config.model.d_model (utils/commons.py:151-155), which configs/models/glow_tts.yaml does not
+        # have: the Noam scale of a GlowTTS run is its encoder width
+        dim = config.model.get("d_model", None) or config.model.encoder.hidden_channels
+        scheduler = S.NoamLR(optimizer, dim_model=dim, warmup_steps=sched.warmup_steps)
     elif sched.name == "linear":
         scheduler = S.LinearWarmupLR(optimizer, warmup_steps=sched.warmup_steps)
     elif sched.name == "cosine":

@@ -548,13 +548,74 @@ def gen_transformer_lm():
          **{"param." + k: v for k, v in params.items()}, **grads)
 
 
+def gen_glow_tts():
+    """models/glow_tts/glow_tts.py:12-130, the reference's own GlowTTS (TextEncoder + FlowSpecDecoder + numpy maximum_path +
+    MLE / duration losses) on a small configuration: hidden 64, 2 heads, 2 encoder layers, relative window 4, prenet, WN kernel 3 with dilation rate 2,
+    mean_only false (so that proj_s / x_logs are exercised); 2 flow blocks of 2 WN layers over 8 mels x n_sqz 2, n_split 4;
+    every dropout 0 (the reference draws from torch's global RNG), ragged token and frame lengths.  `models.parser` needs
+    inflect / unidecode and a CMUdict file, none of which exist here, and none of which is on the scored path: a name-only
+    in-memory module provides `CMUDictParser` and the model is fed token ids directly.  The `end` convolutions of the coupling
+    blocks and the prenet's `proj` start at zero in the reference (the flows would be identities): they are perturbed, like
+    every other parameter, so that all gradients are informative.  Captured: losses, alignment, z_dec, logdet, every gradient,
+    and an eval-mode reconstruction with the noise tensor captured."""
+    from oracle import glow_oracle as go
+    if not hasattr(np, "bool"):
+        np.bool = bool
+    parser = types.ModuleType("models.parser")
+    parser.CMUDictParser = lambda path: None
+    sys.modules.setdefault("models.parser", parser)
+    from models.glow_tts.glow_tts import GlowTTS
+    enc = dict(n_vocab=20, hidden_channels=64, filter_channels=128, filter_channels_dp=64, kernel_size=3, p_dropout=0.0,
+               n_layers=2, n_heads=2, window_size=4, prenet=True, mean_only=False)
+    dec = dict(hidden_channels=64, kernel_size=3, n_blocks=2, n_layers=2, n_sqz=2, n_split=4, sigmoid_scale=False, p_dropout=0.0,
+               dilation_rate=2)
+    cfg = wrap({"model": dict(n_speakers=1, gin_channels=0, encoder=enc, decoder=dec),
+                "dataset": dict(n_mels=8, intersperse_blanks=False, cmudict_path="")})
+    torch.manual_seed(131)
+    model = GlowTTS(cfg)
+    g = torch.Generator().manual_seed(132)
+    with torch.no_grad():
+        for name, prm in model.named_parameters():
+            prm.add_(torch.randn(prm.shape, generator=g) * (0.05 if ".end." in name or ".proj." in name else 0.02))
+    # the prenet's relu_drop is nn.Dropout(0.1) whatever p_dropout says (modules.py:62): switch it off for a deterministic fixture
+    model.encoder.pre.relu_drop[1].p = 0.0
+    tokens, x_lens, y, y_lens = go.synthetic_batch(3, 11, 46, 20, 8, seed=133)
+    model.train()
+    loss_dict, _ = model(tokens, x_lens, y, y_lens)
+    loss_dict["loss"].backward()
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    grads = {"grad." + k: v.grad.detach().clone() for k, v in model.named_parameters()}
+    # the restatement against the reference (float64 restatement vs float32 reference)
+    p64 = {k: v.double() for k, v in params.items()}
+    ocfg = dict(encoder=enc, decoder=dec)
+    out, aux = go.glow_tts_forward(tokens, x_lens, y.double(), y_lens, p64, ocfg, True)
+    print("  oracle vs ref: loss_mle", float(out["loss_mle"]) - loss_dict["loss_mle"].item(), "loss_length",
+          float(out["loss_length"]) - loss_dict["loss_length"].item())
+    assert abs(float(out["loss_mle"]) - loss_dict["loss_mle"].item()) < 1e-5
+    assert abs(float(out["loss_length"]) - loss_dict["loss_length"].item()) < 1e-5
+    # eval mode with the noise captured (glow_tts.py:103-112 draws torch.randn_like)
+    model.eval()
+    with torch.no_grad():
+        torch.manual_seed(134)
+        ev, _ = model(tokens, x_lens, y, y_lens)
+        torch.manual_seed(134)
+        noise = torch.randn(3, 8, 46)
+        oe, _ = go.glow_tts_forward(tokens, x_lens, y.double(), y_lens, p64, ocfg, False, noise=noise.double())
+    print("  eval yh oracle vs ref", float((oe["yh"].float() - ev["yh"]).abs().max()), tuple(ev["yh"].shape))
+    assert torch.allclose(oe["yh"].float(), ev["yh"], atol=1e-4)
+    save("glow_tts", tokens=tokens, x_lens=x_lens, y=y, y_lens=y_lens, loss_mle=loss_dict["loss_mle"].detach(),
+         loss_length=loss_dict["loss_length"].detach(), attn=aux["attn"].float(), z_dec=aux["z_dec"].float(),
+         logdet=aux["logdet"].float(), eval_yh=ev["yh"], eval_noise=noise,
+         **{"param." + k: v for k, v in params.items()}, **grads)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     only = set(sys.argv[1:])
     for name, fn in [("stft", gen_stft), ("mel", gen_mel), ("vq", gen_vq), ("vq_forward", gen_vq_forward),
                      ("block", gen_block), ("losses", gen_losses), ("model", gen_model),
                      ("model_train", gen_model_train_krand), ("ema", gen_ema), ("mas", gen_mas), ("stft_inverse", gen_stft_inverse),
-                     ("transformer_lm", gen_transformer_lm)]:
+                     ("transformer_lm", gen_transformer_lm), ("glow_tts", gen_glow_tts)]:
         if only and name not in only:
             continue
         print(f"[{name}]")

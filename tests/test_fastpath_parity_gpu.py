@@ -80,7 +80,7 @@ def test_gated_hifi_w64_fast_kernels_train_mode_vs_oracle(dtype):
         # none of the dilated convs / their gradients fell back to the streaming or generic kernels
         assert not any(n.startswith(("conv_gemm_dma", "conv1x1_dma", "conv_wgrad_dma")) or n == "conv_wgrad" for n in names), sorted(names)
     else:
-        assert all(n.split(":")[0] in ("conv_gemm", "conv_wgrad", "gate_mix_fwd", "gate_mix_bwd") for n in names), sorted(names)
+        assert all(n.split(":")[0] in ("conv_gemm", "conv_wgrad", "conv_wgrad_reduce", "gate_mix_fwd", "gate_mix_bwd") for n in names), sorted(names)
 
     sd = {k: v.detach().cpu() for k, v in blk.state_dict().items()}
     prm = {"b." + k: v.clone().requires_grad_(True) for k, v in sd.items()}

@@ -244,7 +244,9 @@ def test_eval_reconstructs_audio_from_the_argmax_codes_and_sample_runs(tmp_path)
     assert q.shape == (3, 6) and int(q.min()) >= 0 and int(q.max()) < 16 and audio.shape == (3, 6 * 128)
     assert torch.isfinite(audio).all()
     # the script's default --n_steps (1024, as in the reference) walks prefixes longer than 512 tokens
-    audio, q = model.sample(batch_size=1, n_steps=520, device=DEV, sigma=1.0)
+    long_model, _ = _build(tmp_path / "long", **{**SMALL, "max_len": 600})
+    long_model.eval()
+    audio, q = long_model.sample(batch_size=1, n_steps=520, device=DEV, sigma=1.0)
     assert q.shape == (1, 520) and audio.shape == (1, 520 * 128) and torch.isfinite(audio).all()
 
 

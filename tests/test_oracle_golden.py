@@ -279,3 +279,30 @@ def test_transformer_lm_oracle_dropout_sites_are_unbiased():
     assert abs(float(a.mean()) - 1.0) < 0.02 and set(a.unique().tolist()) == {0.0, float(np.float32(1) / np.float32(0.9))}
     assert not torch.equal(a, b)                                    # sites draw different masks
     assert torch.equal(lmo.CounterDropout(seed=3, p=0.0)(1, x), x)
+
+
+def test_glow_tts_oracle_matches_reference_golden(golden):
+    """oracle/glow_oracle.py (float64) against the reference's own GlowTTS (tests/golden/glow_tts.npz): losses, the
+    alignment found by the monotonic search, the latent, the log-determinants and every parameter gradient."""
+    import torch
+    from oracle import glow_oracle as go
+    g = golden("glow_tts")
+    params = {k[len("param."):]: torch.from_numpy(g[k]).double().requires_grad_(True) for k in g if k.startswith("param.")}
+    cfg = go.GOLDEN_CFG
+    out, aux = go.glow_tts_forward(torch.from_numpy(g["tokens"]), torch.from_numpy(g["x_lens"]), torch.from_numpy(g["y"]).double(),
+                                   torch.from_numpy(g["y_lens"]), params, cfg, True)
+    assert np.isclose(float(out["loss_mle"]), float(g["loss_mle"]), rtol=1e-5) and np.isclose(float(out["loss_length"]), float(g["loss_length"]), rtol=1e-5)
+    assert np.array_equal(aux["attn"].numpy().astype(np.float32), g["attn"])
+    assert np.allclose(aux["z_dec"].detach().numpy(), g["z_dec"], atol=1e-5) and np.allclose(aux["logdet"].detach().numpy(), g["logdet"], rtol=1e-5)
+    out["loss"].backward()
+    checked = 0
+    for k in g:
+        if k.startswith("grad."):
+            ref, got = g[k], params[k[len("grad."):]].grad
+            assert got is not None and np.linalg.norm(got.numpy() - ref) <= 1e-4 * np.linalg.norm(ref) + 1e-7, k
+            checked += 1
+    assert checked > 80
+    ev, _ = go.glow_tts_forward(torch.from_numpy(g["tokens"]), torch.from_numpy(g["x_lens"]), torch.from_numpy(g["y"]).double(),
+                                torch.from_numpy(g["y_lens"]), {k: v.detach() for k, v in params.items()}, cfg, False,
+                                noise=torch.from_numpy(g["eval_noise"]).double())
+    assert np.allclose(ev["yh"].numpy(), g["eval_yh"], atol=1e-4)

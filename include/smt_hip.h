@@ -78,10 +78,11 @@ int smt_vq_backward(const float* x, const float* x_d, const float* row_mask, con
 /* Codebook EMA statistics, BottleneckBlock.update_k (bottleneck.py:64-68):
  * _k_sum = onehot @ x, _k_elem = onehot.sum(-1) over UNMASKED rows.
  *   stats [k_bins*dim + k_bins] f32: sums then counts; written by this call.
- * The scatter-add runs in 64-bit fixed point (units of 2^-24, integer atomics) inside `workspace` and is converted once:
- * the sums are bit-reproducible from run to run whatever order the rows arrive in.  Exact for |x| < 2^15 on a 2^-24 grid
- * (saturating beyond 2^39 units per element). */
-size_t smt_vq_ema_accumulate_workspace_bytes(int k_bins, int dim);
+ * The rows are grouped by code first (counting sort, LDS-privatised histograms) and each wave sums a share of the sorted
+ * order in registers: one 64-bit fixed-point integer atomic (units of 2^-24) per channel per (share, code) boundary, not per
+ * row -- so the time does not depend on how skewed the code usage is, and the sums are bit-reproducible whatever order the
+ * rows arrive in.  Exact for |x| < 2^15 on a 2^-24 grid (saturating beyond 2^39 units per element).  k_bins <= 16384. */
+size_t smt_vq_ema_accumulate_workspace_bytes(int64_t n_rows, int k_bins, int dim);
 int smt_vq_ema_accumulate(const float* x, const int64_t* idx, const float* row_mask,
                           int64_t n_rows, int k_bins, int dim, float* stats, void* workspace, size_t workspace_bytes,
                           smt_stream_t stream);

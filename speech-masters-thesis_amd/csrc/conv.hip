@@ -1037,8 +1037,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <int NTAPS>
 __global__ __launch_bounds__(WS_NT) void conv_ws_pipe_kernel(ConvArgs p, const __bf16* __restrict__ zero_page,
                                                              int tiles_per_wg, int buf_bytes) {
-  typedef __bf16 T;
-  constexpr int EPV = 8, BM = WS_BM, BN = 128, KC = 128, NT = WS_NT, MW = BM / 32, ROWB = KC * 2;
+  constexpr int BM = WS_BM, BN = 128, KC = 128, NT = WS_NT, MW = BM / 32, ROWB = KC * 2;
   constexpr int NSTEP = NTAPS * (KC / 16), NGAP = NSTEP * MW;
   constexpr int PH_UNIT = 12, PH_ROW = 4 * PH_UNIT + 2, PH_TILE = MW * PH_ROW;
   constexpr int AGPR_TAPS = NTAPS < 8 ? NTAPS : 8;
@@ -1270,8 +1269,7 @@ constexpr int WS2_MAX_TAPS = 3;
 template <int NTAPS, int MODE>
 __global__ __launch_bounds__(WS2_NT) void conv_ws2_kernel(ConvArgs p, const __bf16* __restrict__ zero_page,
                                                           int tiles_per_wg, int buf_bytes) {
-  typedef __bf16 T;
-  constexpr int BM = WS_BM, BN = 128, KC = 128, NT = WS2_NT, MW = 2, ROWB = KC * 2;
+  constexpr int BM = WS_BM, BN = 128, KC = 128, MW = 2, ROWB = KC * 2;
   constexpr int NSTEP = NTAPS * (KC / 16), NG = 5;          // NG: 4-row staging groups per wave (<= 160 rows per tile)
   static_assert(MODE == 1 || MODE == 2, "two epilogues");
   // Register budget at two waves per SIMD: 256 per lane, which the compiler splits 128 AccVGPRs / 128 VGPRs as soon as a

@@ -33,14 +33,23 @@ __device__ __forceinline__ cplx fft_twiddle(const cplx* __restrict__ tw, int idx
   return w;
 }
 
-template <int N>
-__device__ __forceinline__ cplx* fft_lds(cplx* a, cplx* b, const cplx* __restrict__ tw, bool inverse) {
+// NT threads cooperate on one transform: 256 = the whole workgroup (a barrier per pass), 64 = ONE WAVE per frame -- a wave's
+// LDS operations execute in order, so its passes need no barrier at all, and a workgroup carries four independent frames
+// (round 3: the one-frame-per-workgroup form spent most of its time in the five or six barriers of a transform).
+template <int NT>
+__device__ __forceinline__ void fft_sync() {
+  if constexpr (NT == 256) __syncthreads();
+  else { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); }
+}
+
+template <int N, int NT>
+__device__ __forceinline__ cplx* fft_lds(cplx* a, cplx* b, const cplx* __restrict__ tw, bool inverse, int tid) {
   cplx* in = a; cplx* out = b;
   int ns = 1;
 #pragma unroll 1
   for (; ns * 4 <= N; ns <<= 2) {
     const int tw_stride = N / (4 * ns);
-    for (int j = threadIdx.x; j < N / 4; j += 256) {
+    for (int j = tid; j < N / 4; j += NT) {
       const int k = j & (ns - 1);
       const cplx u0 = in[j];
       const cplx u1 = cmul(in[j + N / 4], fft_twiddle<N>(tw, k * tw_stride, inverse));
@@ -57,12 +66,12 @@ __device__ __forceinline__ cplx* fft_lds(cplx* a, cplx* b, const cplx* __restric
       out[j0 + 2 * ns] = {v0.x - v2.x, v0.y - v2.y};
       out[j0 + 3 * ns] = {v1.x - v3.x, v1.y - v3.y};
     }
-    __syncthreads();
+    fft_sync<NT>();
     cplx* t = in; in = out; out = t;
   }
   if (ns < N) {   // one radix-2 pass left (log2 N odd)
     const int tw_stride = N / (2 * ns);
-    for (int j = threadIdx.x; j < N / 2; j += 256) {
+    for (int j = tid; j < N / 2; j += NT) {
       const int k = j & (ns - 1);
       const cplx w = fft_twiddle<N>(tw, k * tw_stride, inverse);
       const cplx u = in[j];
@@ -71,10 +80,15 @@ __device__ __forceinline__ cplx* fft_lds(cplx* a, cplx* b, const cplx* __restric
       out[j0] = {u.x + v.x, u.y + v.y};
       out[j0 + ns] = {u.x - v.x, u.y - v.y};
     }
-    __syncthreads();
+    fft_sync<NT>();
     cplx* t = in; in = out; out = t;
   }
   return in;
+}
+// old call sites (stft_inverse_kernel): the whole workgroup on one frame
+template <int N>
+__device__ __forceinline__ cplx* fft_lds(cplx* a, cplx* b, const cplx* __restrict__ tw, bool inverse) {
+  return fft_lds<N, 256>(a, b, tw, inverse, (int)threadIdx.x);
 }
 
 __device__ __forceinline__ int reflect_index(int p, int T) {  // F.pad(mode="reflect") source index
@@ -85,22 +99,31 @@ __device__ __forceinline__ int reflect_index(int p, int T) {  // F.pad(mode="ref
 
 // ------------------------------------------------------------- magnitudes ------
 // mag[b, k, f] for k in [0, N/2], f in [0, frames)   (reference layout [B, bins, frames])
-template <int N>
+// Frame geometry of the <N, NT> kernels: 256 / NT frames per workgroup, dynamic LDS = that many [2][N] complex buffers.
+#define SMT_FRAME_PROLOGUE                                                                  \
+  constexpr int FPW = 256 / NT;                                                             \
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];                  \
+  const int sub = threadIdx.x / NT, tid = threadIdx.x % NT;                                 \
+  const int f = blockIdx.x * FPW + sub, b = blockIdx.y;                                     \
+  cplx* buf0 = reinterpret_cast<cplx*>(smem_raw) + (size_t)sub * 2 * N;                     \
+  cplx* buf1 = buf0 + N;                                                                    \
+  if (NT != 256 && f >= frames) return;      /* wave-uniform; the one-wave form has no workgroup barrier */
+
+template <int N, int NT>
 __global__ __launch_bounds__(256) void stft_mag_kernel(const float* __restrict__ x, const float* __restrict__ window,
                                                        const cplx* __restrict__ tw, float* __restrict__ mag, int T,
                                                        int hop, int pad, int frames) {
-  __shared__ cplx buf[2][N];
-  const int f = blockIdx.x, b = blockIdx.y;
+  SMT_FRAME_PROLOGUE
   const float* xb = x + (long long)b * T;
-  for (int n = threadIdx.x; n < N; n += 256) {
+  for (int n = tid; n < N; n += NT) {
     const float w = window[n];
     float v = 0.f;
     if (w != 0.f) v = w * xb[reflect_index(f * hop + n - pad, T)];
-    buf[0][n] = {v, 0.f};
+    buf0[n] = {v, 0.f};
   }
-  __syncthreads();
-  const cplx* Z = fft_lds<N>(buf[0], buf[1], tw, false);
-  for (int k = threadIdx.x; k <= N / 2; k += 256) {
+  fft_sync<NT>();
+  const cplx* Z = fft_lds<N, NT>(buf0, buf1, tw, false, tid);
+  for (int k = tid; k <= N / 2; k += NT) {
     const cplx z = Z[k];
     mag[((long long)b * (N / 2 + 1) + k) * frames + f] = sqrtf(z.x * z.x + z.y * z.y);
   }
@@ -108,34 +131,33 @@ __global__ __launch_bounds__(256) void stft_mag_kernel(const float* __restrict__
 
 // ------------------------------------------------------------- loss forward ----
 // part[b, f, 0] = sum_k ((|Y| - |Yh|) m)^2, part[b, f, 1] = sum_k ((log|Y| - log|Yh|) m)^2  (clamp 1e-5)
-template <int N>
+template <int N, int NT>
 __global__ __launch_bounds__(256) void stft_loss_fwd_kernel(const float* __restrict__ y, const float* __restrict__ yh,
                                                             const int* __restrict__ lens,
                                                             const float* __restrict__ window,
                                                             const cplx* __restrict__ tw, float* __restrict__ part, int T,
                                                             int hop, int pad, int frames) {
-  __shared__ cplx buf[2][N];
+  SMT_FRAME_PROLOGUE
   __shared__ float red[2][4];
-  const int f = blockIdx.x, b = blockIdx.y;
   // frame kept iff the sample under its centre tap is unmasked (losses.py:33-37)
   const int len = lens ? lens[b] : T;
   const bool keep = (N / 2 - pad + f * hop) < len;
   float s_lin = 0.f, s_log = 0.f;
-  if (keep) {  // block-uniform
+  if (keep) {  // uniform over the NT threads of the frame
     const float* yb = y + (long long)b * T;
     const float* hb = yh + (long long)b * T;
-    for (int n = threadIdx.x; n < N; n += 256) {
+    for (int n = tid; n < N; n += NT) {
       const float w = window[n];
       cplx v = {0.f, 0.f};
       if (w != 0.f) {
         const int src = reflect_index(f * hop + n - pad, T);
         v = {w * yb[src], w * hb[src]};
       }
-      buf[0][n] = v;
+      buf0[n] = v;
     }
-    __syncthreads();
-    const cplx* Z = fft_lds<N>(buf[0], buf[1], tw, false);
-    for (int k = threadIdx.x; k <= N / 2; k += 256) {
+    fft_sync<NT>();
+    const cplx* Z = fft_lds<N, NT>(buf0, buf1, tw, false, tid);
+    for (int k = tid; k <= N / 2; k += NT) {
       const cplx a = Z[k], c = Z[(N - k) & (N - 1)];
       const float yr = 0.5f * (a.x + c.x), yi = 0.5f * (a.y - c.y);
       const float hr = 0.5f * (a.y + c.y), hi = -0.5f * (a.x - c.x);
@@ -148,12 +170,17 @@ __global__ __launch_bounds__(256) void stft_loss_fwd_kernel(const float* __restr
   }
   s_lin = wave_sum(s_lin);
   s_log = wave_sum(s_log);
-  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s_lin; red[1][threadIdx.x >> 6] = s_log; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float* o = part + ((long long)b * frames + f) * 2;
-    o[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-    o[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  float* o = part + ((long long)b * frames + f) * 2;
+  if constexpr (NT == 256) {
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s_lin; red[1][threadIdx.x >> 6] = s_log; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      o[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+      o[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+  } else {
+    (void)red;
+    if (tid == 0) { o[0] = s_lin; o[1] = s_log; }
   }
 }
 
@@ -163,34 +190,33 @@ __global__ __launch_bounds__(256) void stft_loss_fwd_kernel(const float* __restr
 // Two kernels: this one leaves every live frame's windowed time-domain gradient row in `rows` [B, frames, N]; the gather
 // kernel below sums, for every sample, the rows that overlap it IN A FIXED ORDER -- an overlap-add with f32 atomics (the
 // first version) made the gradient, and with it the whole train step, differ from run to run in the last bits.
-template <int N>
+template <int N, int NT>
 __global__ __launch_bounds__(256) void stft_loss_bwd_kernel(const float* __restrict__ y, const float* __restrict__ yh,
                                                             const int* __restrict__ lens,
                                                             const float* __restrict__ window,
                                                             const cplx* __restrict__ tw, const float* __restrict__ coef,
                                                             float* __restrict__ rows, int T, int hop, int pad,
                                                             int frames) {
-  __shared__ cplx buf[2][N];
-  const int f = blockIdx.x, b = blockIdx.y;
+  SMT_FRAME_PROLOGUE
   const int len = lens ? lens[b] : T;
-  if (!((N / 2 - pad + f * hop) < len)) return;  // masked frame: no gradient (block-uniform exit); the gather skips its row
+  if (!((N / 2 - pad + f * hop) < len)) return;  // masked frame: no gradient (uniform over the frame's threads); the gather skips its row
   const float* yb = y + (long long)b * T;
   const float* hb = yh + (long long)b * T;
-  for (int n = threadIdx.x; n < N; n += 256) {
+  for (int n = tid; n < N; n += NT) {
     const float w = window[n];
     cplx v = {0.f, 0.f};
     if (w != 0.f) {
       const int src = reflect_index(f * hop + n - pad, T);
       v = {w * yb[src], w * hb[src]};
     }
-    buf[0][n] = v;
+    buf0[n] = v;
   }
-  __syncthreads();
-  cplx* Z = fft_lds<N>(buf[0], buf[1], tw, false);
-  cplx* G = (Z == buf[0]) ? buf[1] : buf[0];
+  fft_sync<NT>();
+  cplx* Z = fft_lds<N, NT>(buf0, buf1, tw, false, tid);
+  cplx* G = (Z == buf0) ? buf1 : buf0;
   const float c_lin = 2.f * coef[2 * b], c_log = 2.f * coef[2 * b + 1];
   // one-sided gradient spectrum into G (upper half zero)
-  for (int k = threadIdx.x; k < N; k += 256) {
+  for (int k = tid; k < N; k += NT) {
     cplx g = {0.f, 0.f};
     if (k <= N / 2) {
       const cplx a = Z[k], c = Z[(N - k) & (N - 1)];
@@ -204,12 +230,12 @@ __global__ __launch_bounds__(256) void stft_loss_bwd_kernel(const float* __restr
     }
     G[k] = g;
   }
-  __syncthreads();
+  fft_sync<NT>();
   // x_grad[n] = w[n] * Re( sum_k G_k e^{+2 pi i k n / N} )
-  cplx* other = (G == buf[0]) ? buf[1] : buf[0];
-  const cplx* R = fft_lds<N>(G, other, tw, true);
+  cplx* other = (G == buf0) ? buf1 : buf0;
+  const cplx* R = fft_lds<N, NT>(G, other, tw, true, tid);
   float* row = rows + ((long long)b * frames + f) * N;
-  for (int n = threadIdx.x; n < N; n += 256) row[n] = window[n] * R[n].x;
+  for (int n = tid; n < N; n += NT) row[n] = window[n] * R[n].x;
 }
 
 // dyh[b, i] = sum of rows[b, f, n] over the (f, n) whose padded position f hop + n - pad reflects onto sample i
@@ -242,29 +268,29 @@ __global__ __launch_bounds__(256) void stft_overlap_gather_kernel(const float* _
 // ------------------------------------------------------------- log-mel ---------
 // mel[b, m, f] = log(max(sum_k basis[m][k] |X_k|, 1e-5)); the triangular filters are sparse, so
 // each mel bin only walks its own band [lo[m], hi[m]).  (MelSpectrogram.forward, transforms.py:61-65)
-template <int N>
+template <int N, int NT>
 __global__ __launch_bounds__(256) void melspec_kernel(const float* __restrict__ x, const float* __restrict__ window,
                                                       const cplx* __restrict__ tw, const float* __restrict__ basis,
                                                       const int* __restrict__ band, float* __restrict__ mel, int T,
                                                       int hop, int pad, int frames, int n_mels) {
-  __shared__ cplx buf[2][N];
-  __shared__ float magn[N / 2 + 1];
-  const int f = blockIdx.x, b = blockIdx.y;
+  SMT_FRAME_PROLOGUE
   const float* xb = x + (long long)b * T;
-  for (int n = threadIdx.x; n < N; n += 256) {
+  for (int n = tid; n < N; n += NT) {
     const float w = window[n];
     float v = 0.f;
     if (w != 0.f) v = w * xb[reflect_index(f * hop + n - pad, T)];
-    buf[0][n] = {v, 0.f};
+    buf0[n] = {v, 0.f};
   }
-  __syncthreads();
-  const cplx* Z = fft_lds<N>(buf[0], buf[1], tw, false);
-  for (int k = threadIdx.x; k <= N / 2; k += 256) {
+  fft_sync<NT>();
+  cplx* Z = fft_lds<N, NT>(buf0, buf1, tw, false, tid);
+  // magnitudes into the buffer the transform did not end in (as floats)
+  float* magn = reinterpret_cast<float*>(Z == buf0 ? buf1 : buf0);
+  for (int k = tid; k <= N / 2; k += NT) {
     const cplx z = Z[k];
     magn[k] = sqrtf(z.x * z.x + z.y * z.y);
   }
-  __syncthreads();
-  for (int m = threadIdx.x; m < n_mels; m += 256) {
+  fft_sync<NT>();
+  for (int m = tid; m < n_mels; m += NT) {
     float s = 0.f;
     const float* row = basis + (long long)m * (N / 2 + 1);
     for (int k = band[2 * m]; k < band[2 * m + 1]; ++k) s = fmaf(row[k], magn[k], s);
@@ -276,12 +302,16 @@ __global__ __launch_bounds__(256) void melspec_kernel(const float* __restrict__ 
 
 using namespace smt;
 
+// NT = 256: the whole workgroup on one frame.  (NT = 64 -- one wave per frame, four frames per workgroup, no barriers in the
+// transform -- is built into the kernels and was measured in round 3: SLOWER, melspec 189 vs 133 us, spectral loss 2.37 vs
+// 2.23 ms/step: two [N] complex LDS buffers per frame cap the occupancy at 8 waves per CU at 1,024 points, and a lone wave
+// pays the LDS latency of every pass in full.)
 #define SMT_FFT_DISPATCH(NFFT, CALL)                                        \
   switch (NFFT) {                                                           \
-    case 256: { constexpr int N = 256; CALL; } break;                       \
-    case 512: { constexpr int N = 512; CALL; } break;                       \
-    case 1024: { constexpr int N = 1024; CALL; } break;                     \
-    case 2048: { constexpr int N = 2048; CALL; } break;                     \
+    case 256: { constexpr int N = 256, NT = 256; (void)NT; CALL; } break;   \
+    case 512: { constexpr int N = 512, NT = 256; (void)NT; CALL; } break;   \
+    case 1024: { constexpr int N = 1024, NT = 256; (void)NT; CALL; } break; \
+    case 2048: { constexpr int N = 2048, NT = 256; (void)NT; CALL; } break; \
     default:                                                                \
       set_error("stft: n_fft=%d unsupported (256, 512, 1024, 2048)", NFFT); \
       return 1;                                                             \
@@ -344,6 +374,15 @@ __global__ __launch_bounds__(256) void stft_inverse_norm_kernel(const float* __r
   }
 }
 
+// launch of an <N, NT> frame kernel: 256 / NT frames per workgroup, that many [2][N] complex LDS buffers (dynamic)
+template <typename K, typename... Args>
+static void frame_launch(K kernel, int n, int nt, int frames, int batch, hipStream_t stream, Args... args) {
+  const int fpw = 256 / nt;
+  const size_t lds = (size_t)fpw * 2 * n * sizeof(cplx);
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  kernel<<<dim3((frames + fpw - 1) / fpw, batch), 256, lds, stream>>>(args...);
+}
+
 static int stft_frames(int T, int n_fft, int hop) { return (T + 2 * ((n_fft - hop) / 2) - n_fft) / hop + 1; }
 
 extern "C" int smt_stft_num_frames(int t, int n_fft, int hop) { return stft_frames(t, n_fft, hop); }
@@ -356,9 +395,8 @@ extern "C" int smt_stft_magnitude(const float* x, const float* window, const flo
   SMT_CHECK_ARG(t > pad, "smt_stft_magnitude: signal shorter than the reflect padding");
   const int frames = stft_frames(t, n_fft, hop);
   if (batch == 0 || frames <= 0) return 0;
-  dim3 grid(frames, batch);
-  SMT_FFT_DISPATCH(n_fft, (stft_mag_kernel<N><<<grid, 256, 0, stream>>>(x, window, (const cplx*)twiddle, mag, t, hop,
-                                                                      pad, frames)));
+  SMT_FFT_DISPATCH(n_fft, (frame_launch(stft_mag_kernel<N, NT>, N, NT, frames, batch, stream, x, window, (const cplx*)twiddle, mag, t, hop,
+                                        pad, frames)));
   SMT_CHECK_LAUNCH("stft_mag");
   return 0;
 }
@@ -372,9 +410,8 @@ extern "C" int smt_stft_loss_fwd(const float* y, const float* yh, const int* len
   SMT_CHECK_ARG(t > pad, "smt_stft_loss_fwd: signal shorter than the reflect padding");
   const int frames = stft_frames(t, n_fft, hop);
   if (batch == 0 || frames <= 0) return 0;
-  dim3 grid(frames, batch);
-  SMT_FFT_DISPATCH(n_fft, (stft_loss_fwd_kernel<N><<<grid, 256, 0, stream>>>(y, yh, lens, window, (const cplx*)twiddle,
-                                                                           partial, t, hop, pad, frames)));
+  SMT_FFT_DISPATCH(n_fft, (frame_launch(stft_loss_fwd_kernel<N, NT>, N, NT, frames, batch, stream, y, yh, lens, window, (const cplx*)twiddle,
+                                        partial, t, hop, pad, frames)));
   SMT_CHECK_LAUNCH("stft_loss_fwd");
   return 0;
 }
@@ -397,9 +434,8 @@ extern "C" int smt_stft_loss_bwd(const float* y, const float* yh, const int* len
   SMT_CHECK_ARG(workspace && workspace_bytes >= smt_stft_loss_bwd_workspace_bytes(batch, t, n_fft, hop),
                 "smt_stft_loss_bwd: workspace too small");
   float* rows = (float*)workspace;
-  dim3 grid(frames, batch);
-  SMT_FFT_DISPATCH(n_fft, (stft_loss_bwd_kernel<N><<<grid, 256, 0, stream>>>(y, yh, lens, window, (const cplx*)twiddle,
-                                                                           coef, rows, t, hop, pad, frames)));
+  SMT_FFT_DISPATCH(n_fft, (frame_launch(stft_loss_bwd_kernel<N, NT>, N, NT, frames, batch, stream, y, yh, lens, window, (const cplx*)twiddle,
+                                        coef, rows, t, hop, pad, frames)));
   SMT_CHECK_LAUNCH("stft_loss_bwd");
   stft_overlap_gather_kernel<<<dim3((t + 255) / 256, batch), 256, 0, stream>>>(rows, lens, dyh, t, n_fft, hop, pad, frames);
   SMT_CHECK_LAUNCH("stft_overlap_gather");
@@ -415,9 +451,8 @@ extern "C" int smt_melspec(const float* x, const float* window, const float* twi
   SMT_CHECK_ARG(t > pad, "smt_melspec: signal shorter than the reflect padding");
   const int frames = stft_frames(t, n_fft, hop);
   if (batch == 0 || frames <= 0) return 0;
-  dim3 grid(frames, batch);
-  SMT_FFT_DISPATCH(n_fft, (melspec_kernel<N><<<grid, 256, 0, stream>>>(x, window, (const cplx*)twiddle, mel_basis, band,
-                                                                     mel, t, hop, pad, frames, n_mels)));
+  SMT_FFT_DISPATCH(n_fft, (frame_launch(melspec_kernel<N, NT>, N, NT, frames, batch, stream, x, window, (const cplx*)twiddle, mel_basis, band,
+                                        mel, t, hop, pad, frames, n_mels)));
   SMT_CHECK_LAUNCH("melspec");
   return 0;
 }

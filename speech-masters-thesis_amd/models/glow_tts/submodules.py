@@ -56,7 +56,8 @@ def _cin_ok(c):
 def conv(x, weight, bias, *, padding=0, dilation=1, lens=None, residual=None, x_channels=None):
     """Conv1d on channels-last rows.  ``x`` may be wider than the layer's input (``x_channels`` = how many leading channels the
     layer reads): channel counts the MFMA kernel does not take (80 mels) are run as the next admissible count with zero weights
-    on the extra channels -- exact, and the rows are already in memory.  Output channel counts are padded the same way."""
+    on the extra channels -- exact, and the rows are already in memory.  Output channel counts are padded the same way (zero
+    weight rows; the extra output channels are sliced off), because the data gradient reads them as ITS input channels."""
     c_out, c_in, _ = weight.shape
     if x_channels is None:
         x_channels = x.shape[-1]
@@ -67,7 +68,9 @@ def conv(x, weight, bias, *, padding=0, dilation=1, lens=None, residual=None, x_
     assert c_use <= x.shape[-1], f"{c_in} input channels need padding to {c_use}, the rows have {x.shape[-1]}"
     if c_use != c_in:
         weight = F.pad(weight, (0, 0, 0, c_use - c_in))
-    o_use = (c_out + 3) // 4 * 4
+    o_use = c_out                      # the data gradient is a convolution over the OUTPUT channels: same admissible counts
+    while not _cin_ok(o_use):
+        o_use += 8 - o_use % 8 if o_use % 8 else 8
     if o_use != c_out:
         weight = F.pad(weight, (0, 0, 0, 0, 0, o_use - c_out))
         bias = F.pad(bias, (0, o_use - c_out)) if bias is not None else None

@@ -31,7 +31,7 @@ _SIGNATURES = {
     "smt_vq_forward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size,
                                c_ptr]),
     "smt_vq_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
-    "smt_vq_ema_accumulate_workspace_bytes": (c_size, [c_int, c_int]),
+    "smt_vq_ema_accumulate_workspace_bytes": (c_size, [c_i64, c_int, c_int]),
     "smt_vq_ema_accumulate": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_size, c_ptr]),
     "smt_vq_ema_apply": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_int, c_int, c_ptr, c_ptr, c_size,
                                  c_ptr]),

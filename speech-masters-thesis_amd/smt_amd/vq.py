@@ -92,7 +92,7 @@ def ema_stats_numel(k_bins, dim):
 def ema_accumulate(x, idx, row_mask, k_bins, stats):
     n, d = x.shape
     lib = N.lib()
-    ws_bytes = lib.smt_vq_ema_accumulate_workspace_bytes(k_bins, d)
+    ws_bytes = lib.smt_vq_ema_accumulate_workspace_bytes(n, k_bins, d)
     ws = N.workspace.get(ws_bytes, x.device)
     with profiler.region("vq_ema_accumulate", nbytes=n * (4 * d + 8) + 8 * k_bins * (d + 1), bound="hbm"):
         N.check(lib.smt_vq_ema_accumulate(N.ptr(x), N.ptr(idx), N.ptr(row_mask), n, k_bins, d, N.ptr(stats), N.ptr(ws),

@@ -41,6 +41,7 @@ def test_glow_tts_matches_the_reference_golden(golden):
     g = golden("glow_tts")
     params = {k[len("param."):]: torch.from_numpy(g[k]) for k in g if k.startswith("param.")}
     model = _build(go.GOLDEN_CFG, 8, params)
+    model.encoder.pre.p_dropout = 0.0        # the prenet's dropout is 0.1 whatever the config says (modules.py:62); the fixture switched it off
     assert set(model.state_dict()) == set(params)                       # the reference's state-dict names, all of them
     tokens, x_lens = torch.from_numpy(g["tokens"]).to(DEV), torch.from_numpy(g["x_lens"]).to(DEV)
     y, y_lens = torch.from_numpy(g["y"]).to(DEV), torch.from_numpy(g["y_lens"]).to(DEV)
@@ -51,9 +52,11 @@ def test_glow_tts_matches_the_reference_golden(golden):
     assert np.isclose(loss_dict["loss_mle"].item(), float(g["loss_mle"]), rtol=1e-5), (loss_dict["loss_mle"].item(), float(g["loss_mle"]))
     assert np.isclose(loss_dict["loss_length"].item(), float(g["loss_length"]), rtol=1e-5)
     worst = (0.0, "")
+    gmax = max(float(np.linalg.norm(g[k])) for k in g if k.startswith("grad."))
     for name, prm in model.named_parameters():
         assert prm.grad is not None, name
-        e = rel(prm.grad, g["grad." + name])
+        ref = torch.from_numpy(g["grad." + name]).double()
+        e = float((prm.grad.double().cpu() - ref).norm() / (ref.norm() + 1e-6 * gmax))     # floor: see the key-bias note below
         worst = max(worst, (e, name))
         assert e <= 2e-3, (name, e)
     print(f"\n[glow_tts golden] loss_mle {loss_dict['loss_mle'].item():.6f} (ref {float(g['loss_mle']):.6f}); worst gradient rel-L2 {worst}")
@@ -134,8 +137,12 @@ def test_train_mode_with_dropout_matches_the_oracle():
     assert np.isclose(loss_dict["loss_mle"].item(), float(out["loss_mle"]), rtol=1e-4)
     assert np.isclose(loss_dict["loss_length"].item(), float(out["loss_length"]), rtol=1e-4)
     worst = (0.0, "")
+    gmax = max(float(v.grad.norm()) for v in p64.values())
     for name, prm in model.named_parameters():
-        e = rel(prm.grad, p64[name].grad)
+        ref = p64[name].grad
+        # relative L2 per tensor, with an absolute floor: the key bias of an attention layer has an exactly zero gradient
+        # (softmax is invariant to a constant added to all keys' scores), which fp32 reproduces as ~1e-9, not as 0
+        e = float((prm.grad.double().cpu() - ref).norm() / (ref.norm() + 1e-6 * gmax))
         worst = max(worst, (e, name))
     print(f"  worst gradient rel-L2 {worst}")
     assert worst[0] <= 5e-3, worst

@@ -14,4 +14,4 @@ void set_error(const char* fmt, ...) {
 }  // namespace smt
 
 extern "C" const char* smt_last_error(void) { return smt::g_err; }
-extern "C" int smt_abi_version(void) { return 2; }
+extern "C" int smt_abi_version(void) { return 3; }

@@ -9,7 +9,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SMT_HIP_LIB: an alternative build of the same ABI (tools/ablate_*.sh link their -D ablation builds to libsmt_hip_abl.so)
 LIB_PATH = os.environ.get("SMT_HIP_LIB") or os.path.join(_HERE, "libsmt_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 _lock = threading.Lock()

@@ -33,10 +33,11 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0
 
 def parse(argv=None):
     p = argparse.ArgumentParser()
-    p.add_argument("--workload", choices=["vqvae", "transformer_lm", "aux"], default="vqvae",
+    p.add_argument("--workload", choices=["vqvae", "transformer_lm", "aux", "glow_tts"], default="vqvae",
                    help="vqvae = the headline metric (BASELINE.json); transformer_lm = the SURVEY 8(f2) train step, reported "
                         "in the same format under its own metric name; aux = the SURVEY 8(f1)/(f3)/(f4) paths (encode-only "
                         "pass, STFT.inverse, monotonic alignment search), each with its roofline and its CPU leg")
+    p.add_argument("--tts_batch", type=int, default=32, help="glow_tts workload: utterances per GPU (scripts/train_glow_tts.sh trains with 32)")
     p.add_argument("--lm_batch", type=int, default=8, help="sequences per GPU (scripts/train_transformer_lm.sh: 8)")
     p.add_argument("--lm_len", type=int, default=258, help="tokens per sequence (<bos> + 256 codes + pad)")
     p.add_argument("--lm_tune_gemm", action="store_true",
@@ -255,6 +256,112 @@ def lm_main(args, rank, world, device, rehearsal):
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def glow_main(args, rank, world, device):
+    """`--workload glow_tts`: utterances/s of the GlowTTS train step (BASELINE.json configs[4]) on the reference's
+    configuration (configs/models/glow_tts.yaml: 6-layer relative-attention encoder, 12 flow blocks x 4 WN layers over 80 mels
+    x n_sqz 2), synthetic LJSpeech-shaped (token, mel) pairs (configs/datasets/synthetic_tts.yaml), fp32, AdamW + Noam, dropout
+    on; data parallel like the headline run.  CPU leg: the oracle's forward + backward on this box's host cores."""
+    from smt_amd import native, profiler
+    from smt_amd.dist import GradSync
+    native.lib()
+    from utils import config as C
+    from utils.commons import get_model, get_optimizer
+    from datasets.synthetic import SyntheticTTS
+    import train as trainlib
+    cfg = C.merge(C.load(os.path.join(PKG, "configs/models/glow_tts.yaml")), C.load(os.path.join(PKG, "configs/datasets/synthetic_tts.yaml")),
+                  C.create({"train": {"batch_size": args.tts_batch, "n_gpus": world, "ema": False, "grad_clip_norm": None, "seed": 0,
+                                      "log_dir": "/tmp/smt_bench_tts"}}))
+    torch.manual_seed(0)
+    model, ema = get_model(cfg, device, rank)
+    optimizer, scheduler = get_optimizer(cfg, model)
+    grad_sync = GradSync([p for p in model.parameters() if p.requires_grad], timing=True) if world > 1 else None
+    ds = SyntheticTTS(cfg, "train")
+    pool, frames, tokens = [], 0, 0
+    for bi in range(4):
+        items = [ds[(rank * 4 + bi) * args.tts_batch + i] for i in range(args.tts_batch)]
+        batch = SyntheticTTS.collate(items)
+        frames += int(batch[3].sum()); tokens += int(batch[1].sum())
+        pool.append([b.to(device) if torch.is_tensor(b) else b for b in batch])
+    model.train()
+
+    def step(i):
+        return trainlib.train_step(global_step=i, batch=pool[i % len(pool)], config=cfg, model=model, ema=ema, optimizer=optimizer,
+                                   scheduler=scheduler, device=device, rank=rank, grad_sync=grad_sync)
+    for i in range(args.warmup):
+        step(i)
+    profiler.reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_prof = 0
+    for i in range(args.steps):
+        prof = (not args.no_kernel_events) and i % max(1, args.event_every) == 0
+        profiler.enable(prof); n_prof += int(prof)
+        loss_dict, _ = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    profiler.enable(False)
+    if world > 1:
+        mine = torch.tensor([elapsed], device=device)
+        every_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every_rank, mine)
+        elapsed = max(t.item() for t in every_rank)
+    if rank == 0:
+        kernels = profiler.summary()
+        convs = [k for k in kernels if k["name"].startswith(("conv_gemm", "conv_wgrad"))]
+        tot_us = sum(k["total_ms"] for k in convs) * 1e3
+        flops = sum(k["alg_flops"] * k["launches"] for k in convs)
+        roofline = None if not convs or tot_us == 0 else {
+            "kernel": "smt::conv_gemm_kernel<float> / conv_wgrad_kernel<float> (every convolution of the model, forward + both gradients)",
+            "bound": "mfma", "achieved": flops / tot_us * 1e-6, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": flops / tot_us * 1e-6 / F32_MFMA_PEAK_TFLOPS, "traffic": None, "ms_per_step": tot_us * 1e-3 / max(1, n_prof),
+            "note": "fp32 matrix pipe (v_mfma_f32_32x32x2_f32), 160-channel flows and 192-channel hidden layers on 128-row tiles; the step "
+                    "is ~2,000 small launches and host-paced"}
+        line = {"metric": "GlowTTS train utterances/sec (SURVEY 8(f4), BASELINE.json configs[4]; not the headline)",
+                "value": args.tts_batch * world * args.steps / elapsed, "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"models/glow_tts (configs/models/glow_tts.yaml), batch {args.tts_batch}/GPU, mean {tokens / (4 * args.tts_batch):.0f} tokens / "
+                                       f"{frames / (4 * args.tts_batch):.0f} mel frames per utterance, fp32, AdamW + Noam, dropout on",
+                           "global_batch": args.tts_batch * world, "parallelism": f"dp{world}"},
+                "loss": float(loss_dict["loss"].detach()), "native_launches_per_step": sum(k["launches"] for k in kernels) / max(1, n_prof),
+                "native_kernel_ms_per_step": sum(k["total_ms"] for k in kernels) / max(1, n_prof), "roofline": roofline, "kernels": kernels}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = glow_cpu_baseline(cfg)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def glow_cpu_baseline(cfg):
+    """The GlowTTS oracle (oracle/glow_oracle.py: the reference's forward restated, torch-CPU fp32, autograd backward, numpy
+    alignment search as in the reference) on this box's host cores: 4 utterances, one warm-up + 3 timed passes, median."""
+    import statistics
+    from oracle import glow_oracle as go
+    cores = usable_cpus()
+    torch.set_num_threads(cores)
+    m = cfg.model.to_dict()
+    ocfg = dict(encoder=m["encoder"], decoder=m["decoder"], zero_out=False)
+    params = {k: v.requires_grad_(True) for k, v in go.init_params(ocfg, 149, 80, seed=0).items()}
+    tokens, x_lens, y, y_lens = go.synthetic_batch(4, 120, 620, 149, 80, seed=1)
+    times = []
+    for i in range(4):
+        t0 = time.perf_counter()
+        out, _ = go.glow_tts_forward(tokens, x_lens, y, y_lens, params, ocfg, True)
+        out["loss"].backward()
+        for v in params.values():
+            v.grad = None
+        if i:
+            times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return {"value": 4 / med, "unit": "utterances/s", "cores": cores, "threads": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle forward + backward (no optimizer, dropout off), fp32 torch-CPU, 4 utterances of <= 120 tokens / 620 frames, "
+                      f"1 warm-up + 3 timed, median {med:.2f} s"}
 
 
 def _timed(fn, steps, warmup):
@@ -575,6 +682,8 @@ def main(argv=None):
         return graph_leg_main(args, device)
     if args.workload == "transformer_lm":
         return lm_main(args, rank, world, device, rehearsal)
+    if args.workload == "glow_tts":
+        return glow_main(args, rank, world, device)
     if args.workload == "aux":
         if world != 1:
             sys.exit("bench.py --workload aux is a single-GPU measurement")

@@ -36,6 +36,25 @@ __global__ __launch_bounds__(GL_NT) void gl_colsum_kernel(const float* __restric
   out[c] = s;
 }
 
+// the same in two stages for many chunks: slice s of GL_SLICES sums its contiguous range of chunks, then the slices are summed
+constexpr int GL_SLICES = 64;
+__global__ __launch_bounds__(GL_NT) void gl_colsum_slice_kernel(const float* __restrict__ part, int nchunks, int stride, int ncol,
+                                                                float* __restrict__ scratch) {
+  const int c = blockIdx.x * GL_NT + threadIdx.x, sl = blockIdx.y;
+  if (c >= ncol) return;
+  const int per = (nchunks + GL_SLICES - 1) / GL_SLICES, k0 = sl * per, k1 = min(nchunks, k0 + per);
+  float s = 0.f;
+  for (int k = k0; k < k1; ++k) s += part[(size_t)k * stride + c];
+  scratch[(size_t)sl * ncol + c] = s;
+}
+static int gl_colsum_big(const float* part, int nchunks, int stride, int ncol, float* out, float* scratch, hipStream_t stream) {
+  gl_colsum_slice_kernel<<<dim3((ncol + GL_NT - 1) / GL_NT, GL_SLICES), GL_NT, 0, stream>>>(part, nchunks, stride, ncol, scratch);
+  SMT_CHECK_LAUNCH("glow_colsum_slice");
+  gl_colsum_kernel<<<(ncol + GL_NT - 1) / GL_NT, GL_NT, 0, stream>>>(scratch, GL_SLICES, ncol, ncol, out);
+  SMT_CHECK_LAUNCH("glow_colsum");
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ ActNorm
 __global__ __launch_bounds__(GL_NT) void gl_actnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ logs,
                                                                const float* __restrict__ bias, const int* __restrict__ lens,
@@ -668,8 +687,9 @@ extern "C" int smt_glow_attention_fwd(const float* q, const float* k, const floa
 }
 
 extern "C" size_t smt_glow_attention_bwd_workspace_bytes(int batch, int t, int heads, int head_dim, int window) {
-  // score gradients [B, heads, T, T] + per-query partials of the two relative-embedding gradients
-  return ((size_t)batch * heads * t * t + 2 * (size_t)batch * heads * t * (2 * window + 1) * head_dim) * sizeof(float);
+  // score gradients [B, heads, T, T] + per-query partials of the two relative-embedding gradients + the reduction's slices
+  return ((size_t)batch * heads * t * t + 2 * (size_t)batch * heads * t * (2 * window + 1) * head_dim +
+          (size_t)GL_SLICES * (2 * window + 1) * head_dim) * sizeof(float);
 }
 
 extern "C" int smt_glow_attention_bwd(const float* q, const float* k, const float* v, const float* emb_rel_k, const float* emb_rel_v,
@@ -696,11 +716,10 @@ extern "C" int smt_glow_attention_bwd(const float* q, const float* k, const floa
     SMT_CHECK_LAUNCH("glow_attention_bwd_kv");
   }
   // the relative embeddings are shared by batch items, heads and queries: fixed-order sums of the per-query partials
-  gl_colsum_kernel<<<(nrel + GL_NT - 1) / GL_NT, GL_NT, 0, stream>>>(dkp, batch * heads * t, nrel, nrel, demb_rel_k);
-  SMT_CHECK_LAUNCH("glow_colsum");
-  gl_colsum_kernel<<<(nrel + GL_NT - 1) / GL_NT, GL_NT, 0, stream>>>(dvp, batch * heads * t, nrel, nrel, demb_rel_v);
-  SMT_CHECK_LAUNCH("glow_colsum");
-  return 0;
+  float* scratch = dvp + (size_t)batch * heads * t * nrel;
+  int rc = gl_colsum_big(dkp, batch * heads * t, nrel, nrel, demb_rel_k, scratch, stream);
+  if (rc) return rc;
+  return gl_colsum_big(dvp, batch * heads * t, nrel, nrel, demb_rel_v, scratch, stream);
 }
 
 extern "C" int smt_glow_prior_logp(const float* x_m, const float* x_logs, const float* z, float* logp, int batch, int t_x, int t_y,

@@ -15,6 +15,7 @@ transposed-fragment kernel (conv_wgrad.hip) with a fixed-order reduction.
 import contextlib
 import ctypes
 import functools
+import weakref
 from dataclasses import dataclass
 from typing import Optional
 
@@ -109,23 +110,52 @@ class _PackCache:
     each (weights, layout) pair gets a persistent destination and a row in a device-side table; the first use after an
     update -- announced by mark_packed_weights_dirty() (every training forward and every optimizer step do) or noticed
     through a moved ``_version`` -- repacks ALL rows with smt_pack_weights_batched.
-    Source tensors are held strongly so that an address can never be reused by a different tensor behind a key."""
+    Only ``nn.Parameter`` sources are cached, and they are held WEAKLY: an entry whose parameter has died (a model that was
+    dropped) is pruned, and a new tensor that happens to reuse the address gets a fresh entry.  Weights computed on the fly
+    (weight-normed convolutions, padded or sliced weights: a new tensor every step) are packed per use and never stored --
+    cached, they would pile up a dead entry per step (round 3: GlowTTS reached 18 ms per repack before this rule)."""
 
     MAX_ENTRIES = 8192
 
     def __init__(self):
-        self.entries = {}        # key -> dict(dst, parts=[(weight, PackEntry)], versions)
+        self.entries = {}        # key -> dict(dst, parts=[(weakref to the weight, PackEntry)], versions)
         self.order = []          # keys in table order
-        self.table = None        # (table_dev, block_entry_dev, block_local_dev, n_blocks, n_rows)
-        self.device = None
+        self.table = None        # {device: (table_dev, block_entry_dev, block_local_dev, n_blocks)}
         self.dirty = False       # set by mark_packed_weights_dirty(): repack on the next use whatever the versions say
         self.generation = 0      # number of mark_packed_weights_dirty() calls (tests)
-        self.epoch = 0           # moves when the copies are thrown away (invalidate / overflow): graphs check it
+        self.epoch = 0           # moves when copies are thrown away (pruning / overflow): captured graphs check it
         self.repacks = 0         # batched repack launches so far (tests)
+
+    @staticmethod
+    def _versions(e):
+        """Version counters of the live sources, or None if one of them has died."""
+        out = []
+        for ref, _ in e["parts"]:
+            w = ref()
+            if w is None:
+                return None
+            out.append(w._version)
+        return out
+
+    def _drop(self, key):
+        del self.entries[key]
+        self.order.remove(key)
+        self.table = None
+        self.epoch += 1
+
+    def prune(self):
+        """Forget the copies of parameters that no longer exist."""
+        for key in [k for k, e in self.entries.items() if self._versions(e) is None]:
+            self._drop(key)
 
     def get(self, key, build):
         e = self.entries.get(key)
+        if e is not None and self._versions(e) is None:      # the address was reused by a new tensor
+            self._drop(key)
+            e = None
         if e is None:
+            if len(self.entries) >= self.MAX_ENTRIES:
+                self.prune()
             if len(self.entries) >= self.MAX_ENTRIES:
                 self.entries.clear(); self.order.clear(); self.table = None
                 self.epoch += 1
@@ -134,10 +164,24 @@ class _PackCache:
             self.order.append(key)
             self.table = None
             self._launch([e])                       # first use: pack just this operand
-            e["versions"] = [w._version for w, _ in e["parts"]]
+            e["versions"] = self._versions(e)
             return e["dst"]
-        if self.dirty or e["versions"] != [w._version for w, _ in e["parts"]]:
+        if self.dirty or e["versions"] != self._versions(e):
             self.repack_all()
+        return e["dst"]
+
+    def pack_once(self, e):
+        """Pack an operand that is not cached (its source is not a parameter).  A single-part operand in the default layout
+        goes through smt_pack_weight (arguments by value: no table upload)."""
+        if len(e["parts"]) == 1:
+            _, pe = e["parts"][0]
+            if pe.dst_offset == 0 and pe.dst_tap_stride == pe.n_out * pe.n_in and pe.dst_row_stride == pe.n_in:
+                taps = (ctypes.c_int * pe.taps)(*[pe.tap_map[i] for i in range(pe.taps)])
+                N.check(N.lib().smt_pack_weight(ctypes.c_void_p(pe.src), ctypes.c_void_p(pe.dst), pe.dtype, pe.n_out, pe.n_in, pe.taps,
+                                                pe.stride_out, pe.stride_in, pe.stride_tap, taps, pe.swizzle, N.stream_ptr()),
+                        "smt_pack_weight")
+                return e["dst"]
+        self._launch([e])
         return e["dst"]
 
     def _upload(self, entries):
@@ -163,6 +207,7 @@ class _PackCache:
         return table, be, bl, nb
 
     def repack_all(self):
+        self.prune()
         entries = [self.entries[k] for k in self.order]
         by_dev = {}
         for e in entries:
@@ -173,7 +218,7 @@ class _PackCache:
             with profiler.region("pack_weights_batched", bound="hbm"):
                 self.table[dev] = self._launch(es, self.table.get(dev))
             for e in es:
-                e["versions"] = [w._version for w, _ in e["parts"]]
+                e["versions"] = self._versions(e)
         self.dirty = False
         self.repacks += 1
 
@@ -268,9 +313,11 @@ def _pack_parts(parts, dtype, dst_shape):
             assert not swizzle or (dtype == torch.bfloat16 and n_in % 128 == 0)
             for i, t in enumerate(tap_map):
                 pe.tap_map[i] = t
-            ps.append((w, pe))
+            ps.append((weakref.ref(w), pe))
         return {"dst": dst, "parts": ps, "versions": None}
 
+    if not all(isinstance(p[0], torch.nn.Parameter) for p in parts):
+        return _pack_cache.pack_once(build())      # a computed weight (weight norm, padding, a slice): new tensor every step
     return _pack_cache.get(key, build)
 
 

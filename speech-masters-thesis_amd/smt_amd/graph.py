@@ -56,6 +56,7 @@ class GraphedStep:
         import gc
         import warnings
         gc.collect()                           # drop unreachable autograd graphs of earlier iterations (see above)
+        convops._pack_cache.prune()            # ... and the packed copies of models that no longer exist
         stale = stale_autograd_graphs(list(model.parameters()))
         if stale:
             raise RuntimeError(

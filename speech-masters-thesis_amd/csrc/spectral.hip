@@ -21,6 +21,15 @@ namespace smt {
 struct cplx { float x, y; };
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 
+// LDS index of element i of a frame.  The one-wave transform (NT = 64) writes its first pass at stride R (16 or 8 complex =
+// 128 / 64 bytes) between lanes -- a 32- / 16-way bank conflict on a dense array -- so its frames carry one pad slot per R
+// elements: the stride becomes R + 1 complex (34 / 18 dwords, conflict-free over a half-wave), and the second pass's four
+// 16-lane groups land in four disjoint bank quarters.  The whole-workgroup form (NT = 256) keeps the dense layout.
+template <int N, int NT>
+__device__ __forceinline__ constexpr int fidx(int i) { return NT == 64 ? i + (i >> (N == 512 ? 3 : 4)) : i; }
+template <int N>
+constexpr int frame_padded() { return N + (N >> (N == 512 ? 3 : 4)); }
+
 // Stockham autosort FFT, radix-4 passes (plus one radix-2 pass when log2 N is odd): half the passes -- and barriers --
 // of a radix-2 transform; this kernel is bound by the LDS round trip + barrier per pass, not by bandwidth.
 // Input in `a`, result pointer returned (a or b).  tw[k] = exp(-2 pi i k / N), k < N/2; inverse => conjugate twiddles.
@@ -42,8 +51,15 @@ __device__ __forceinline__ void fft_sync() {
   else { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); }
 }
 
+template <int N, bool INV>
+__device__ __forceinline__ void fft_wave(cplx* buf, const cplx* __restrict__ tw, int lane);
+
 template <int N, int NT>
 __device__ __forceinline__ cplx* fft_lds(cplx* a, cplx* b, const cplx* __restrict__ tw, bool inverse, int tid) {
+  if constexpr (NT == 64) {       // one wave per frame: in place, high radix (below); b is not used
+    if (inverse) fft_wave<N, true>(a, tw, tid); else fft_wave<N, false>(a, tw, tid);
+    return a;
+  }
   cplx* in = a; cplx* out = b;
   int ns = 1;
 #pragma unroll 1
@@ -91,6 +107,94 @@ __device__ __forceinline__ cplx* fft_lds(cplx* a, cplx* b, const cplx* __restric
   return fft_lds<N, 256>(a, b, tw, inverse, (int)threadIdx.x);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// One wave per frame, in place, high radix (round 3).  The whole-workgroup transform above spends its time in the LDS round
+// trip + barrier of every radix-4 pass (5-6 per frame, one butterfly per thread).  Here a wave owns a frame: a lane holds the
+// R inputs of a radix-R butterfly in registers (16 loads in flight), so 512 / 1,024 / 2,048 points take 3 passes
+// (8.8.8 / 16.16.4 / 16.16.8) instead of 5-6, no workgroup barrier at all (a wave's LDS operations execute in order), and one
+// [N] buffer per frame: every lane reads all its inputs before it writes, so the Stockham pass runs in place.
+template <int R, bool INV>
+struct SmallDft;
+template <bool INV>
+struct SmallDft<1, INV> { static __device__ __forceinline__ void run(cplx (&)[1]) {} };
+// twiddles of the small DFTs: exp(-2 pi i m / 16), m = 0..7 (forward); the inverse conjugates.  Functions of a constant after
+// unrolling, so they fold into literals.
+__device__ __forceinline__ constexpr float cos16(int m) {
+  return m == 0 ? 1.f : m == 1 ? 0.92387953251128674f : m == 2 ? 0.70710678118654752f : m == 3 ? 0.38268343236508977f
+       : m == 4 ? 0.f : m == 5 ? -0.38268343236508977f : m == 6 ? -0.70710678118654752f : -0.92387953251128674f;
+}
+__device__ __forceinline__ constexpr float sin16(int m) {
+  return m == 0 ? 0.f : m == 1 ? 0.38268343236508977f : m == 2 ? 0.70710678118654752f : m == 3 ? 0.92387953251128674f
+       : m == 4 ? 1.f : m == 5 ? 0.92387953251128674f : m == 6 ? 0.70710678118654752f : 0.38268343236508977f;
+}
+template <int R, bool INV>
+struct SmallDft {
+  // natural-order DFT of R points in registers by radix-2 decimation in time (R = 2, 4, 8, 16), fully unrolled
+  static __device__ __forceinline__ void run(cplx (&v)[R]) {
+    cplx e[R / 2], o[R / 2];
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) { e[i] = v[2 * i]; o[i] = v[2 * i + 1]; }
+    SmallDft<R / 2, INV>::run(e);
+    SmallDft<R / 2, INV>::run(o);
+#pragma unroll
+    for (int q = 0; q < R / 2; ++q) {
+      cplx t;
+      if (q == 0) t = o[q];
+      else if (4 * q == R) t = INV ? cplx{-o[q].y, o[q].x} : cplx{o[q].y, -o[q].x};      // times -i (forward), +i (inverse)
+      else {
+        const float c = cos16(q * (16 / R)), sn = sin16(q * (16 / R));
+        const cplx w = {c, INV ? sn : -sn};
+        t = cmul(o[q], w);
+      }
+      v[q] = {e[q].x + t.x, e[q].y + t.y};
+      v[q + R / 2] = {e[q].x - t.x, e[q].y - t.y};
+    }
+  }
+};
+
+// one in-place Stockham pass of radix R over buf[N] by one wave; ns = product of the radices of the earlier passes
+template <int N, int R, bool INV>
+__device__ __forceinline__ void fft_wave_pass(cplx* buf, const cplx* __restrict__ tw, int ns, int lane) {
+  constexpr int NB = N / R;                     // butterflies
+  constexpr int PER = (NB + 63) / 64;           // per lane
+  cplx u[PER][R];
+  const int tw_stride = N / (R * ns);
+#pragma unroll
+  for (int p = 0; p < PER; ++p) {
+    const int j = lane + 64 * p;
+    if (NB % 64 == 0 || j < NB) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) u[p][r] = buf[fidx<N, 64>(j + r * NB)];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int p = 0; p < PER; ++p) {
+    const int j = lane + 64 * p;
+    if (NB % 64 == 0 || j < NB) {
+      const int k = j & (ns - 1);
+      if (ns > 1) {
+#pragma unroll
+        for (int r = 1; r < R; ++r) u[p][r] = cmul(u[p][r], fft_twiddle<N>(tw, r * k * tw_stride, INV));
+      }
+      SmallDft<R, INV>::run(u[p]);
+      const int j0 = (j - k) * R + k;
+#pragma unroll
+      for (int q = 0; q < R; ++q) buf[fidx<N, 64>(j0 + q * ns)] = u[p][q];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+}
+template <int N, bool INV>
+__device__ __forceinline__ void fft_wave(cplx* buf, const cplx* __restrict__ tw, int lane) {
+  static_assert(N == 256 || N == 512 || N == 1024 || N == 2048, "built sizes");
+  if constexpr (N == 256) { fft_wave_pass<N, 16, INV>(buf, tw, 1, lane); fft_wave_pass<N, 16, INV>(buf, tw, 16, lane); }
+  if constexpr (N == 512) { fft_wave_pass<N, 8, INV>(buf, tw, 1, lane); fft_wave_pass<N, 8, INV>(buf, tw, 8, lane); fft_wave_pass<N, 8, INV>(buf, tw, 64, lane); }
+  if constexpr (N == 1024) { fft_wave_pass<N, 16, INV>(buf, tw, 1, lane); fft_wave_pass<N, 16, INV>(buf, tw, 16, lane); fft_wave_pass<N, 4, INV>(buf, tw, 256, lane); }
+  if constexpr (N == 2048) { fft_wave_pass<N, 16, INV>(buf, tw, 1, lane); fft_wave_pass<N, 16, INV>(buf, tw, 16, lane); fft_wave_pass<N, 8, INV>(buf, tw, 256, lane); }
+}
+
 __device__ __forceinline__ int reflect_index(int p, int T) {  // F.pad(mode="reflect") source index
   if (p < 0) p = -p;
   if (p >= T) p = 2 * (T - 1) - p;
@@ -99,32 +203,37 @@ __device__ __forceinline__ int reflect_index(int p, int T) {  // F.pad(mode="ref
 
 // ------------------------------------------------------------- magnitudes ------
 // mag[b, k, f] for k in [0, N/2], f in [0, frames)   (reference layout [B, bins, frames])
-// Frame geometry of the <N, NT> kernels: 256 / NT frames per workgroup, dynamic LDS = that many [2][N] complex buffers.
-#define SMT_FRAME_PROLOGUE                                                                  \
+// Frame geometry of the <N, NT> kernels: 256 / NT frames per workgroup.  Dynamic LDS per frame: two [N] complex buffers in
+// the whole-workgroup form; ONE in the one-wave form (its transform runs in place) plus SCRATCH complex slots behind it
+// (buf1) for the kernels that need a second array.
+template <int N, int NT>
+constexpr int frame_slots(int scratch) { return NT == 256 ? 2 * N : frame_padded<N>() + scratch; }
+#define SMT_FRAME_PROLOGUE(SCRATCH)                                                         \
   constexpr int FPW = 256 / NT;                                                             \
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];                  \
   const int sub = threadIdx.x / NT, tid = threadIdx.x % NT;                                 \
   const int f = blockIdx.x * FPW + sub, b = blockIdx.y;                                     \
-  cplx* buf0 = reinterpret_cast<cplx*>(smem_raw) + (size_t)sub * 2 * N;                     \
-  cplx* buf1 = buf0 + N;                                                                    \
+  cplx* buf0 = reinterpret_cast<cplx*>(smem_raw) + (size_t)sub * frame_slots<N, NT>(SCRATCH); \
+  cplx* buf1 = buf0 + (NT == 256 ? N : frame_padded<N>());                                  \
+  (void)buf1;                                                                               \
   if (NT != 256 && f >= frames) return;      /* wave-uniform; the one-wave form has no workgroup barrier */
 
 template <int N, int NT>
 __global__ __launch_bounds__(256) void stft_mag_kernel(const float* __restrict__ x, const float* __restrict__ window,
                                                        const cplx* __restrict__ tw, float* __restrict__ mag, int T,
                                                        int hop, int pad, int frames) {
-  SMT_FRAME_PROLOGUE
+  SMT_FRAME_PROLOGUE(0)
   const float* xb = x + (long long)b * T;
+#pragma unroll 8
   for (int n = tid; n < N; n += NT) {
     const float w = window[n];
-    float v = 0.f;
-    if (w != 0.f) v = w * xb[reflect_index(f * hop + n - pad, T)];
-    buf0[n] = {v, 0.f};
+    const float xv = xb[reflect_index(f * hop + n - pad, T)];
+    buf0[fidx<N, NT>(n)] = {w != 0.f ? w * xv : 0.f, 0.f};
   }
   fft_sync<NT>();
   const cplx* Z = fft_lds<N, NT>(buf0, buf1, tw, false, tid);
   for (int k = tid; k <= N / 2; k += NT) {
-    const cplx z = Z[k];
+    const cplx z = Z[fidx<N, NT>(k)];
     mag[((long long)b * (N / 2 + 1) + k) * frames + f] = sqrtf(z.x * z.x + z.y * z.y);
   }
 }
@@ -137,7 +246,7 @@ __global__ __launch_bounds__(256) void stft_loss_fwd_kernel(const float* __restr
                                                             const float* __restrict__ window,
                                                             const cplx* __restrict__ tw, float* __restrict__ part, int T,
                                                             int hop, int pad, int frames) {
-  SMT_FRAME_PROLOGUE
+  SMT_FRAME_PROLOGUE(0)
   __shared__ float red[2][4];
   // frame kept iff the sample under its centre tap is unmasked (losses.py:33-37)
   const int len = lens ? lens[b] : T;
@@ -146,19 +255,17 @@ __global__ __launch_bounds__(256) void stft_loss_fwd_kernel(const float* __restr
   if (keep) {  // uniform over the NT threads of the frame
     const float* yb = y + (long long)b * T;
     const float* hb = yh + (long long)b * T;
+#pragma unroll 8
     for (int n = tid; n < N; n += NT) {
       const float w = window[n];
-      cplx v = {0.f, 0.f};
-      if (w != 0.f) {
-        const int src = reflect_index(f * hop + n - pad, T);
-        v = {w * yb[src], w * hb[src]};
-      }
-      buf0[n] = v;
+      const int src = reflect_index(f * hop + n - pad, T);
+      const float a = yb[src], c = hb[src];
+      buf0[fidx<N, NT>(n)] = w != 0.f ? cplx{w * a, w * c} : cplx{0.f, 0.f};
     }
     fft_sync<NT>();
     const cplx* Z = fft_lds<N, NT>(buf0, buf1, tw, false, tid);
     for (int k = tid; k <= N / 2; k += NT) {
-      const cplx a = Z[k], c = Z[(N - k) & (N - 1)];
+      const cplx a = Z[fidx<N, NT>(k)], c = Z[fidx<N, NT>((N - k) & (N - 1))];
       const float yr = 0.5f * (a.x + c.x), yi = 0.5f * (a.y - c.y);
       const float hr = 0.5f * (a.y + c.y), hi = -0.5f * (a.x - c.x);
       const float my = sqrtf(yr * yr + yi * yi), mh = sqrtf(hr * hr + hi * hi);
@@ -197,45 +304,43 @@ __global__ __launch_bounds__(256) void stft_loss_bwd_kernel(const float* __restr
                                                             const cplx* __restrict__ tw, const float* __restrict__ coef,
                                                             float* __restrict__ rows, int T, int hop, int pad,
                                                             int frames) {
-  SMT_FRAME_PROLOGUE
+  SMT_FRAME_PROLOGUE(0)
   const int len = lens ? lens[b] : T;
   if (!((N / 2 - pad + f * hop) < len)) return;  // masked frame: no gradient (uniform over the frame's threads); the gather skips its row
   const float* yb = y + (long long)b * T;
   const float* hb = yh + (long long)b * T;
+#pragma unroll 8
   for (int n = tid; n < N; n += NT) {
     const float w = window[n];
-    cplx v = {0.f, 0.f};
-    if (w != 0.f) {
-      const int src = reflect_index(f * hop + n - pad, T);
-      v = {w * yb[src], w * hb[src]};
-    }
-    buf0[n] = v;
+    const int src = reflect_index(f * hop + n - pad, T);
+    const float a = yb[src], c = hb[src];
+    buf0[fidx<N, NT>(n)] = w != 0.f ? cplx{w * a, w * c} : cplx{0.f, 0.f};
   }
   fft_sync<NT>();
   cplx* Z = fft_lds<N, NT>(buf0, buf1, tw, false, tid);
-  cplx* G = (Z == buf0) ? buf1 : buf0;
+  // one-sided gradient spectrum (upper half zero).  Whole-workgroup form: into the other buffer.  One-wave form: IN PLACE,
+  // bin k and its mirror N - k are read and rewritten by the same lane in the same iteration, and no later iteration
+  // (larger k) reads a slot an earlier one wrote (those are < k or > N - k).
+  cplx* G = NT == 64 ? Z : ((Z == buf0) ? buf1 : buf0);
   const float c_lin = 2.f * coef[2 * b], c_log = 2.f * coef[2 * b + 1];
-  // one-sided gradient spectrum into G (upper half zero)
-  for (int k = tid; k < N; k += NT) {
-    cplx g = {0.f, 0.f};
-    if (k <= N / 2) {
-      const cplx a = Z[k], c = Z[(N - k) & (N - 1)];
-      const float yr = 0.5f * (a.x + c.x), yi = 0.5f * (a.y - c.y);
-      const float hr = 0.5f * (a.y + c.y), hi = -0.5f * (a.x - c.x);
-      const float my = sqrtf(yr * yr + yi * yi), mh = sqrtf(hr * hr + hi * hi);
-      float dmag = -c_lin * (my - mh);
-      if (mh > 1e-5f) dmag -= c_log * (__logf(fmaxf(my, 1e-5f)) - __logf(mh)) / mh;
-      const float inv = mh > 0.f ? dmag / mh : 0.f;
-      g = {inv * hr, inv * hi};
-    }
-    G[k] = g;
+  for (int k = tid; k <= N / 2; k += NT) {
+    const int km = (N - k) & (N - 1);
+    const cplx a = Z[fidx<N, NT>(k)], c = Z[fidx<N, NT>(km)];
+    const float yr = 0.5f * (a.x + c.x), yi = 0.5f * (a.y - c.y);
+    const float hr = 0.5f * (a.y + c.y), hi = -0.5f * (a.x - c.x);
+    const float my = sqrtf(yr * yr + yi * yi), mh = sqrtf(hr * hr + hi * hi);
+    float dmag = -c_lin * (my - mh);
+    if (mh > 1e-5f) dmag -= c_log * (__logf(fmaxf(my, 1e-5f)) - __logf(mh)) / mh;
+    const float inv = mh > 0.f ? dmag / mh : 0.f;
+    if (km != k) G[fidx<N, NT>(km)] = {0.f, 0.f};
+    G[fidx<N, NT>(k)] = {inv * hr, inv * hi};
   }
   fft_sync<NT>();
   // x_grad[n] = w[n] * Re( sum_k G_k e^{+2 pi i k n / N} )
   cplx* other = (G == buf0) ? buf1 : buf0;
   const cplx* R = fft_lds<N, NT>(G, other, tw, true, tid);
   float* row = rows + ((long long)b * frames + f) * N;
-  for (int n = tid; n < N; n += NT) row[n] = window[n] * R[n].x;
+  for (int n = tid; n < N; n += NT) row[n] = window[n] * R[fidx<N, NT>(n)].x;
 }
 
 // dyh[b, i] = sum of rows[b, f, n] over the (f, n) whose padded position f hop + n - pad reflects onto sample i
@@ -273,27 +378,40 @@ __global__ __launch_bounds__(256) void melspec_kernel(const float* __restrict__ 
                                                       const cplx* __restrict__ tw, const float* __restrict__ basis,
                                                       const int* __restrict__ band, float* __restrict__ mel, int T,
                                                       int hop, int pad, int frames, int n_mels) {
-  SMT_FRAME_PROLOGUE
+  SMT_FRAME_PROLOGUE(N / 2)              // one-wave form: N floats behind the frame for the magnitudes
   const float* xb = x + (long long)b * T;
+#pragma unroll 8
   for (int n = tid; n < N; n += NT) {
     const float w = window[n];
-    float v = 0.f;
-    if (w != 0.f) v = w * xb[reflect_index(f * hop + n - pad, T)];
-    buf0[n] = {v, 0.f};
+    const float xv = xb[reflect_index(f * hop + n - pad, T)];
+    buf0[fidx<N, NT>(n)] = {w != 0.f ? w * xv : 0.f, 0.f};
   }
   fft_sync<NT>();
   cplx* Z = fft_lds<N, NT>(buf0, buf1, tw, false, tid);
   // magnitudes into the buffer the transform did not end in (as floats)
   float* magn = reinterpret_cast<float*>(Z == buf0 ? buf1 : buf0);
   for (int k = tid; k <= N / 2; k += NT) {
-    const cplx z = Z[k];
+    const cplx z = Z[fidx<N, NT>(k)];
     magn[k] = sqrtf(z.x * z.x + z.y * z.y);
   }
   fft_sync<NT>();
+  // a lane walks the band of its mel bin (up to ~60 bins at the top of the scale): eight independent basis loads per trip, so
+  // the walk costs band/8 L2 round trips instead of one per bin (the one-load-per-trip form was most of this kernel's time)
   for (int m = tid; m < n_mels; m += NT) {
     float s = 0.f;
     const float* row = basis + (long long)m * (N / 2 + 1);
-    for (int k = band[2 * m]; k < band[2 * m + 1]; ++k) s = fmaf(row[k], magn[k], s);
+    const int lo = band[2 * m], hi = band[2 * m + 1];
+    for (int k = lo; k < hi; k += 8) {
+      float w[8], v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int kk = min(k + u, hi - 1);
+        w[u] = row[kk];
+        v[u] = magn[kk];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s = fmaf(k + u < hi ? w[u] : 0.f, v[u], s);      // same order of additions as before
+    }
     mel[((long long)b * n_mels + m) * frames + f] = logf(fmaxf(s, 1e-5f));
   }
 }
@@ -302,16 +420,23 @@ __global__ __launch_bounds__(256) void melspec_kernel(const float* __restrict__ 
 
 using namespace smt;
 
-// NT = 256: the whole workgroup on one frame.  (NT = 64 -- one wave per frame, four frames per workgroup, no barriers in the
-// transform -- is built into the kernels and was measured in round 3: SLOWER, melspec 189 vs 133 us, spectral loss 2.37 vs
-// 2.23 ms/step: two [N] complex LDS buffers per frame cap the occupancy at 8 waves per CU at 1,024 points, and a lone wave
-// pays the LDS latency of every pass in full.)
+// NT = 64: one wave per frame, four frames per workgroup, in-place radix-8/16 passes (fft_wave).  SMT_FFT_NT=256 in the
+// environment selects the round-2 form (the whole workgroup on one frame, radix-4 passes over two buffers) for A/B runs.
+// (Round 3 first tried the one-wave form WITH the radix-4 two-buffer transform: slower, melspec 189 vs 133 us -- two [N]
+// buffers per frame capped the occupancy at 8 waves per CU and a lone wave paid the LDS latency of each of the 5-6 passes.)
+static int fft_nt() {
+  static const int nt = [] { const char* e = getenv("SMT_FFT_NT"); return (e && atoi(e) == 256) ? 256 : 64; }();
+  return nt;
+}
+#define SMT_FFT_DISPATCH_NT(NN, CALL)                                       \
+  if (fft_nt() == 256) { constexpr int N = NN, NT = 256; (void)NT; CALL; }  \
+  else { constexpr int N = NN, NT = 64; (void)NT; CALL; }
 #define SMT_FFT_DISPATCH(NFFT, CALL)                                        \
   switch (NFFT) {                                                           \
-    case 256: { constexpr int N = 256, NT = 256; (void)NT; CALL; } break;   \
-    case 512: { constexpr int N = 512, NT = 256; (void)NT; CALL; } break;   \
-    case 1024: { constexpr int N = 1024, NT = 256; (void)NT; CALL; } break; \
-    case 2048: { constexpr int N = 2048, NT = 256; (void)NT; CALL; } break; \
+    case 256: { SMT_FFT_DISPATCH_NT(256, CALL) } break;                     \
+    case 512: { SMT_FFT_DISPATCH_NT(512, CALL) } break;                     \
+    case 1024: { SMT_FFT_DISPATCH_NT(1024, CALL) } break;                   \
+    case 2048: { SMT_FFT_DISPATCH_NT(2048, CALL) } break;                   \
     default:                                                                \
       set_error("stft: n_fft=%d unsupported (256, 512, 1024, 2048)", NFFT); \
       return 1;                                                             \
@@ -374,11 +499,11 @@ __global__ __launch_bounds__(256) void stft_inverse_norm_kernel(const float* __r
   }
 }
 
-// launch of an <N, NT> frame kernel: 256 / NT frames per workgroup, that many [2][N] complex LDS buffers (dynamic)
+// launch of an <N, NT> frame kernel: 256 / NT frames per workgroup, `slots` complex LDS slots per frame (frame_slots)
 template <typename K, typename... Args>
-static void frame_launch(K kernel, int n, int nt, int frames, int batch, hipStream_t stream, Args... args) {
+static void frame_launch(K kernel, int slots, int nt, int frames, int batch, hipStream_t stream, Args... args) {
   const int fpw = 256 / nt;
-  const size_t lds = (size_t)fpw * 2 * n * sizeof(cplx);
+  const size_t lds = (size_t)fpw * slots * sizeof(cplx);
   if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   kernel<<<dim3((frames + fpw - 1) / fpw, batch), 256, lds, stream>>>(args...);
 }
@@ -395,7 +520,7 @@ extern "C" int smt_stft_magnitude(const float* x, const float* window, const flo
   SMT_CHECK_ARG(t > pad, "smt_stft_magnitude: signal shorter than the reflect padding");
   const int frames = stft_frames(t, n_fft, hop);
   if (batch == 0 || frames <= 0) return 0;
-  SMT_FFT_DISPATCH(n_fft, (frame_launch(stft_mag_kernel<N, NT>, N, NT, frames, batch, stream, x, window, (const cplx*)twiddle, mag, t, hop,
+  SMT_FFT_DISPATCH(n_fft, (frame_launch(stft_mag_kernel<N, NT>, frame_slots<N, NT>(0), NT, frames, batch, stream, x, window, (const cplx*)twiddle, mag, t, hop,
                                         pad, frames)));
   SMT_CHECK_LAUNCH("stft_mag");
   return 0;
@@ -410,7 +535,7 @@ extern "C" int smt_stft_loss_fwd(const float* y, const float* yh, const int* len
   SMT_CHECK_ARG(t > pad, "smt_stft_loss_fwd: signal shorter than the reflect padding");
   const int frames = stft_frames(t, n_fft, hop);
   if (batch == 0 || frames <= 0) return 0;
-  SMT_FFT_DISPATCH(n_fft, (frame_launch(stft_loss_fwd_kernel<N, NT>, N, NT, frames, batch, stream, y, yh, lens, window, (const cplx*)twiddle,
+  SMT_FFT_DISPATCH(n_fft, (frame_launch(stft_loss_fwd_kernel<N, NT>, frame_slots<N, NT>(0), NT, frames, batch, stream, y, yh, lens, window, (const cplx*)twiddle,
                                         partial, t, hop, pad, frames)));
   SMT_CHECK_LAUNCH("stft_loss_fwd");
   return 0;
@@ -434,7 +559,7 @@ extern "C" int smt_stft_loss_bwd(const float* y, const float* yh, const int* len
   SMT_CHECK_ARG(workspace && workspace_bytes >= smt_stft_loss_bwd_workspace_bytes(batch, t, n_fft, hop),
                 "smt_stft_loss_bwd: workspace too small");
   float* rows = (float*)workspace;
-  SMT_FFT_DISPATCH(n_fft, (frame_launch(stft_loss_bwd_kernel<N, NT>, N, NT, frames, batch, stream, y, yh, lens, window, (const cplx*)twiddle,
+  SMT_FFT_DISPATCH(n_fft, (frame_launch(stft_loss_bwd_kernel<N, NT>, frame_slots<N, NT>(0), NT, frames, batch, stream, y, yh, lens, window, (const cplx*)twiddle,
                                         coef, rows, t, hop, pad, frames)));
   SMT_CHECK_LAUNCH("stft_loss_bwd");
   stft_overlap_gather_kernel<<<dim3((t + 255) / 256, batch), 256, 0, stream>>>(rows, lens, dyh, t, n_fft, hop, pad, frames);
@@ -451,7 +576,7 @@ extern "C" int smt_melspec(const float* x, const float* window, const float* twi
   SMT_CHECK_ARG(t > pad, "smt_melspec: signal shorter than the reflect padding");
   const int frames = stft_frames(t, n_fft, hop);
   if (batch == 0 || frames <= 0) return 0;
-  SMT_FFT_DISPATCH(n_fft, (frame_launch(melspec_kernel<N, NT>, N, NT, frames, batch, stream, x, window, (const cplx*)twiddle, mel_basis, band,
+  SMT_FFT_DISPATCH(n_fft, (frame_launch(melspec_kernel<N, NT>, frame_slots<N, NT>(N / 2), NT, frames, batch, stream, x, window, (const cplx*)twiddle, mel_basis, band,
                                         mel, t, hop, pad, frames, n_mels)));
   SMT_CHECK_LAUNCH("melspec");
   return 0;

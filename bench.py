@@ -543,11 +543,12 @@ def melspec_roofline(args, audio, device, note):
     us = ms * 1e3
     nbytes = x.numel() * 4 + out.numel() * 4
     note(f"melspec: {us:.1f} us = {nbytes / us * 1e-3:.0f} GB/s")
-    return {"kernel": "smt::melspec_kernel (windowed STFT + mel contraction + log, one launch)", "bound": "hbm",
+    return {"kernel": "smt::melspec_wave_kernel (windowed STFT + mel contraction + log, one launch)", "bound": "hbm",
             "achieved": nbytes / us * 1e-3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / us * 1e-3 / HBM_PEAK_GBS,
             "avg_us": us, "launches_timed": 50, "alg_bytes_per_launch": nbytes, "bytes_per_sample": nbytes / x.numel(),
             "frames": int(out.shape[-1]), "traffic": None,
-            "note": f"batch {x.shape[0]} x {x.shape[1]} samples; not on the VQ-VAE train step (SURVEY D1), measured stand-alone"}
+            "note": f"batch {x.shape[0]} x {x.shape[1]} samples; not on the VQ-VAE train step (SURVEY D1), measured stand-alone; "
+                    "VALU-bound (in-LDS FFT), frac is against the HBM bound of its algorithmic bytes"}
 
 
 def launch_or_none(args, argv):
@@ -824,9 +825,9 @@ def main(argv=None):
         }
         extra_rooflines = {k: v for k, v in extra_rooflines.items() if v is not None}
         if "stft_loss" in extra_rooflines:
-            extra_rooflines["stft_loss"]["note"] = ("not HBM-bound today: one frame per workgroup with a barrier per radix-4 "
-                                                    "pass makes it LDS-latency bound; frac is against the HBM bound its "
-                                                    "algorithmic bytes would allow")
+            extra_rooflines["stft_loss"]["note"] = ("not HBM-bound: one wave per frame, radix-8/16 in-LDS passes; the PMC pass shows the "
+                                                    "vector ALU ~70 % busy (1,430 VALU instructions per 1,024-point frame). "
+                                                    "frac is against the HBM bound its algorithmic bytes would allow")
         if "vq_forward" in extra_rooflines:
             # the north-star kernel against BOTH bounds: HBM by algorithmic bytes (above) and the bf16 matrix pipe by the
             # 3 x 2 N K D FLOP of its filter (its intensity, ~1500 FLOP/B at K = 1024, puts it on the MFMA side)

@@ -334,6 +334,10 @@ int smt_stft_loss_bwd(const float* y, const float* yh, const int* lens, const fl
 int smt_stft_inverse(const float* magnitude, const float* phase, const float* window, const float* twiddle, float* out,
                      int batch, int n_fft, int hop, int frames, smt_stream_t stream);
 
+/* Test hook (no reference counterpart): the one-wave in-LDS transform of the spectral kernels alone on ONE complex frame.
+ * in / out [n_fft][2] f32, twiddle as for smt_stft_magnitude; inverse != 0 uses the conjugate twiddles (no 1/N). */
+int smt_fft_selftest(const float* in, const float* twiddle, float* out, int n_fft, int inverse, smt_stream_t stream);
+
 /* ------------------------------------------------------- TransformerLM ---- */
 /* The kernels between the dense projections of the causal TransformerLM over VQ codes
  * (models/transformer_lm/transformer_lm.py:32-135: nn.TransformerEncoder, post-norm layers, ReLU feed-forward).

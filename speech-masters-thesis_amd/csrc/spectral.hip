@@ -18,15 +18,35 @@
 
 namespace smt {
 
+// SMT_HD: the transform core also compiles for the host, where tests/fft_core_host.cpp runs it lane by lane against a
+// double-precision DFT (pytest -m "not gpu").
+#define SMT_HD __host__ __device__ __forceinline__
 struct cplx { float x, y; };
-__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+SMT_HD cplx cmul(cplx a, cplx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+
+#ifndef SMT_FFT_STAMP
+#define SMT_FFT_STAMP 0   // diagnostic build (tools/fft_phases.sh): cycle sums of the phases of the one-wave frame kernels
+#endif
+#if SMT_FFT_STAMP
+constexpr int FFT_DBG_WAVES = 8192;
+__device__ unsigned long long fft_dbg[FFT_DBG_WAVES * 8];     // one row of phase slots per wave (plain stores)
+#define FFT_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define FFT_ACC(k, a, b)                                                                                     \
+  do {                                                                                                       \
+    const unsigned wid_ = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);                    \
+    if ((threadIdx.x & 63) == 0 && wid_ < FFT_DBG_WAVES) fft_dbg[wid_ * 8 + (k)] = (b) - (a);                \
+  } while (0)
+#else
+#define FFT_T(var) do {} while (0)
+#define FFT_ACC(k, a, b) do {} while (0)
+#endif
 
 // LDS index of element i of a frame.  The one-wave transform (NT = 64) writes its first pass at stride R (16 or 8 complex =
 // 128 / 64 bytes) between lanes -- a 32- / 16-way bank conflict on a dense array -- so its frames carry one pad slot per R
 // elements: the stride becomes R + 1 complex (34 / 18 dwords, conflict-free over a half-wave), and the second pass's four
 // 16-lane groups land in four disjoint bank quarters.  The whole-workgroup form (NT = 256) keeps the dense layout.
 template <int N, int NT>
-__device__ __forceinline__ constexpr int fidx(int i) { return NT == 64 ? i + (i >> (N == 512 ? 3 : 4)) : i; }
+SMT_HD constexpr int fidx(int i) { return NT == 64 ? i + (i >> (N == 512 ? 3 : 4)) : i; }
 template <int N>
 constexpr int frame_padded() { return N + (N >> (N == 512 ? 3 : 4)); }
 
@@ -116,21 +136,21 @@ __device__ __forceinline__ cplx* fft_lds(cplx* a, cplx* b, const cplx* __restric
 template <int R, bool INV>
 struct SmallDft;
 template <bool INV>
-struct SmallDft<1, INV> { static __device__ __forceinline__ void run(cplx (&)[1]) {} };
+struct SmallDft<1, INV> { static SMT_HD void run(cplx (&)[1]) {} };
 // twiddles of the small DFTs: exp(-2 pi i m / 16), m = 0..7 (forward); the inverse conjugates.  Functions of a constant after
 // unrolling, so they fold into literals.
-__device__ __forceinline__ constexpr float cos16(int m) {
+SMT_HD constexpr float cos16(int m) {
   return m == 0 ? 1.f : m == 1 ? 0.92387953251128674f : m == 2 ? 0.70710678118654752f : m == 3 ? 0.38268343236508977f
        : m == 4 ? 0.f : m == 5 ? -0.38268343236508977f : m == 6 ? -0.70710678118654752f : -0.92387953251128674f;
 }
-__device__ __forceinline__ constexpr float sin16(int m) {
+SMT_HD constexpr float sin16(int m) {
   return m == 0 ? 0.f : m == 1 ? 0.38268343236508977f : m == 2 ? 0.70710678118654752f : m == 3 ? 0.92387953251128674f
        : m == 4 ? 1.f : m == 5 ? 0.92387953251128674f : m == 6 ? 0.70710678118654752f : 0.38268343236508977f;
 }
 template <int R, bool INV>
 struct SmallDft {
   // natural-order DFT of R points in registers by radix-2 decimation in time (R = 2, 4, 8, 16), fully unrolled
-  static __device__ __forceinline__ void run(cplx (&v)[R]) {
+  static SMT_HD void run(cplx (&v)[R]) {
     cplx e[R / 2], o[R / 2];
 #pragma unroll
     for (int i = 0; i < R / 2; ++i) { e[i] = v[2 * i]; o[i] = v[2 * i + 1]; }
@@ -191,7 +211,12 @@ __device__ __forceinline__ void fft_wave(cplx* buf, const cplx* __restrict__ tw,
   static_assert(N == 256 || N == 512 || N == 1024 || N == 2048, "built sizes");
   if constexpr (N == 256) { fft_wave_pass<N, 16, INV>(buf, tw, 1, lane); fft_wave_pass<N, 16, INV>(buf, tw, 16, lane); }
   if constexpr (N == 512) { fft_wave_pass<N, 8, INV>(buf, tw, 1, lane); fft_wave_pass<N, 8, INV>(buf, tw, 8, lane); fft_wave_pass<N, 8, INV>(buf, tw, 64, lane); }
-  if constexpr (N == 1024) { fft_wave_pass<N, 16, INV>(buf, tw, 1, lane); fft_wave_pass<N, 16, INV>(buf, tw, 16, lane); fft_wave_pass<N, 4, INV>(buf, tw, 256, lane); }
+  if constexpr (N == 1024) {
+    FFT_T(t0); fft_wave_pass<N, 16, INV>(buf, tw, 1, lane);
+    FFT_T(t1); fft_wave_pass<N, 16, INV>(buf, tw, 16, lane);
+    FFT_T(t2); fft_wave_pass<N, 4, INV>(buf, tw, 256, lane);
+    FFT_T(t3); FFT_ACC(1, t0, t1); FFT_ACC(2, t1, t2); FFT_ACC(3, t2, t3);
+  }
   if constexpr (N == 2048) { fft_wave_pass<N, 16, INV>(buf, tw, 1, lane); fft_wave_pass<N, 16, INV>(buf, tw, 16, lane); fft_wave_pass<N, 8, INV>(buf, tw, 256, lane); }
 }
 
@@ -224,11 +249,14 @@ __global__ __launch_bounds__(256) void stft_mag_kernel(const float* __restrict__
                                                        int hop, int pad, int frames) {
   SMT_FRAME_PROLOGUE(0)
   const float* xb = x + (long long)b * T;
-#pragma unroll 8
+  // window and samples are loaded unconditionally and multiplied (as the reference's windowed basis does): a "skip the
+  // sample where the window is zero" test makes every sample load wait for its window load -- 2 x 16 dependent round trips
+  // per frame, measured as HALF of the one-wave kernel's time (tools/fft_phases.sh)
+#pragma unroll 16
   for (int n = tid; n < N; n += NT) {
     const float w = window[n];
     const float xv = xb[reflect_index(f * hop + n - pad, T)];
-    buf0[fidx<N, NT>(n)] = {w != 0.f ? w * xv : 0.f, 0.f};
+    buf0[fidx<N, NT>(n)] = {w * xv, 0.f};
   }
   fft_sync<NT>();
   const cplx* Z = fft_lds<N, NT>(buf0, buf1, tw, false, tid);
@@ -252,18 +280,21 @@ __global__ __launch_bounds__(256) void stft_loss_fwd_kernel(const float* __restr
   const int len = lens ? lens[b] : T;
   const bool keep = (N / 2 - pad + f * hop) < len;
   float s_lin = 0.f, s_log = 0.f;
+  FFT_T(ts0);
   if (keep) {  // uniform over the NT threads of the frame
     const float* yb = y + (long long)b * T;
     const float* hb = yh + (long long)b * T;
-#pragma unroll 8
+#pragma unroll 16
     for (int n = tid; n < N; n += NT) {
       const float w = window[n];
       const int src = reflect_index(f * hop + n - pad, T);
       const float a = yb[src], c = hb[src];
-      buf0[fidx<N, NT>(n)] = w != 0.f ? cplx{w * a, w * c} : cplx{0.f, 0.f};
+      buf0[fidx<N, NT>(n)] = {w * a, w * c};
     }
     fft_sync<NT>();
+    FFT_T(ts1); FFT_ACC(0, ts0, ts1);
     const cplx* Z = fft_lds<N, NT>(buf0, buf1, tw, false, tid);
+    FFT_T(ts2);
     for (int k = tid; k <= N / 2; k += NT) {
       const cplx a = Z[fidx<N, NT>(k)], c = Z[fidx<N, NT>((N - k) & (N - 1))];
       const float yr = 0.5f * (a.x + c.x), yi = 0.5f * (a.y - c.y);
@@ -274,6 +305,9 @@ __global__ __launch_bounds__(256) void stft_loss_fwd_kernel(const float* __restr
       s_lin = fmaf(d, d, s_lin);
       s_log = fmaf(dl, dl, s_log);
     }
+#if SMT_FFT_STAMP
+    { FFT_T(ts3); FFT_ACC(4, ts2, ts3); FFT_ACC(5, ts0, ts3); FFT_ACC(6, 0ull, 1ull); }
+#endif
   }
   s_lin = wave_sum(s_lin);
   s_log = wave_sum(s_log);
@@ -309,12 +343,12 @@ __global__ __launch_bounds__(256) void stft_loss_bwd_kernel(const float* __restr
   if (!((N / 2 - pad + f * hop) < len)) return;  // masked frame: no gradient (uniform over the frame's threads); the gather skips its row
   const float* yb = y + (long long)b * T;
   const float* hb = yh + (long long)b * T;
-#pragma unroll 8
+#pragma unroll 16
   for (int n = tid; n < N; n += NT) {
     const float w = window[n];
     const int src = reflect_index(f * hop + n - pad, T);
     const float a = yb[src], c = hb[src];
-    buf0[fidx<N, NT>(n)] = w != 0.f ? cplx{w * a, w * c} : cplx{0.f, 0.f};
+    buf0[fidx<N, NT>(n)] = {w * a, w * c};
   }
   fft_sync<NT>();
   cplx* Z = fft_lds<N, NT>(buf0, buf1, tw, false, tid);
@@ -380,11 +414,11 @@ __global__ __launch_bounds__(256) void melspec_kernel(const float* __restrict__ 
                                                       int hop, int pad, int frames, int n_mels) {
   SMT_FRAME_PROLOGUE(N / 2)              // one-wave form: N floats behind the frame for the magnitudes
   const float* xb = x + (long long)b * T;
-#pragma unroll 8
+#pragma unroll 16
   for (int n = tid; n < N; n += NT) {
     const float w = window[n];
     const float xv = xb[reflect_index(f * hop + n - pad, T)];
-    buf0[fidx<N, NT>(n)] = {w != 0.f ? w * xv : 0.f, 0.f};
+    buf0[fidx<N, NT>(n)] = {w * xv, 0.f};
   }
   fft_sync<NT>();
   cplx* Z = fft_lds<N, NT>(buf0, buf1, tw, false, tid);
@@ -414,6 +448,300 @@ __global__ __launch_bounds__(256) void melspec_kernel(const float* __restrict__ 
     }
     mel[((long long)b * n_mels + m) * frames + f] = logf(fmaxf(s, 1e-5f));
   }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// One-wave-per-frame kernels, second step (round 3).  tools/fft_phases.sh showed where the first one-wave form
+// spent a frame: a third in the loads (48 dword loads per lane through the 64 B/clk L1 path), a fifth in pass 2 waiting for
+// its 15 gathered twiddles (whose index arithmetic also cost more VALU than a complex multiply), a fifth in the serial
+// spectra loop.  Here a wave loads ONE twiddle per pass and butterfly (the R - 1 others are its powers, <= 6 roundings
+// deep); interior frames and the window are read as 16-byte pieces (4 consecutive samples per lane); the spectra loop is
+// unrolled.
+#define WAVE_LB (N <= 1024 ? 4 : 2)     // waves per SIMD the LDS frames allow
+struct __attribute__((packed, aligned(4))) f4u { float v[4]; };   // 16-byte load at 4-byte alignment (hop need not divide 4)
+
+template <int N>
+struct WaveFft {
+  static constexpr int R1 = (N == 512) ? 8 : 16;          // passes 1 and 2
+  static constexpr int R3 = N / (R1 * R1);                // pass 3: 8 (512), 4 (1024), 8 (2048), none (256)
+  static constexpr int NB1 = N / R1, PER1 = (NB1 + 63) / 64;
+  static constexpr int NB3 = R3 > 1 ? N / R3 : 64, PER3 = NB3 / 64;
+  cplx w2;                                                // exp(-2 pi i (lane & (R1 - 1)) R3 / N)
+  cplx w3[PER3];                                          // exp(-2 pi i (lane + 64 p) / N)
+
+  SMT_HD void load(const cplx* __restrict__ tw, int lane) {
+    w2 = tw[(lane & (R1 - 1)) * (R3 > 1 ? R3 : 1)];
+#pragma unroll
+    for (int p = 0; p < PER3; ++p) w3[p] = tw[lane + 64 * p];
+  }
+};
+
+SMT_HD void wave_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+#endif
+}
+
+// one pass of one lane: reads `in`, writes `out`; w1[p] = the twiddle of butterfly p of this lane (ignored when ns == 1).
+// On the device in == out (every lane of the wave has read before any lane writes: LDS operations of a wave execute in
+// order); the host test passes a snapshot as `in`.
+template <int N, int R, int PER, bool INV>
+SMT_HD void wave_pass(const cplx* in, cplx* out, int ns, int lane, const cplx (&w1)[PER]) {
+  constexpr int NB = N / R;
+  cplx u[PER][R];
+#pragma unroll
+  for (int p = 0; p < PER; ++p) {
+    const int j = lane + 64 * p;
+    if (NB >= 64 || j < NB) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) u[p][r] = in[fidx<N, 64>(j + r * NB)];
+    }
+  }
+  wave_fence();
+#pragma unroll
+  for (int p = 0; p < PER; ++p) {
+    const int j = lane + 64 * p;
+    if (NB >= 64 || j < NB) {
+      const int k = j & (ns - 1);
+      if (ns > 1) {
+        // u[r] *= w1^r with few registers live: w1, w1^2, w1^3 and a running (w1^4)^a; at most 6 roundings deep
+        cplx wa = w1[p];
+        if (INV) wa.y = -wa.y;
+        const cplx wb = cmul(wa, wa), wc3 = cmul(wb, wa), w4 = cmul(wb, wb);
+        u[p][1] = cmul(u[p][1], wa);
+        if (R > 2) { u[p][2] = cmul(u[p][2], wb); u[p][3] = cmul(u[p][3], wc3); }
+        cplx run = w4;
+#pragma unroll
+        for (int a = 1; a < R / 4; ++a) {
+          u[p][4 * a] = cmul(u[p][4 * a], run);
+          u[p][4 * a + 1] = cmul(u[p][4 * a + 1], cmul(run, wa));
+          u[p][4 * a + 2] = cmul(u[p][4 * a + 2], cmul(run, wb));
+          u[p][4 * a + 3] = cmul(u[p][4 * a + 3], cmul(run, wc3));
+          if (a + 1 < R / 4) run = cmul(run, w4);
+        }
+      }
+      SmallDft<R, INV>::run(u[p]);
+      const int j0 = (j - k) * R + k;
+#pragma unroll
+      for (int q = 0; q < R; ++q) out[fidx<N, 64>(j0 + q * ns)] = u[p][q];
+    }
+  }
+  wave_fence();
+}
+
+template <int N, bool INV>
+__device__ __forceinline__ void wave_fft(cplx* buf, const WaveFft<N>& wc, int lane) {
+  using W = WaveFft<N>;
+  cplx w1a[W::PER1];
+#pragma unroll
+  for (int p = 0; p < W::PER1; ++p) w1a[p] = wc.w2;
+  wave_pass<N, W::R1, W::PER1, INV>(buf, buf, 1, lane, w1a);
+  wave_pass<N, W::R1, W::PER1, INV>(buf, buf, W::R1, lane, w1a);
+  if constexpr (W::R3 > 1) wave_pass<N, W::R3, W::PER3, INV>(buf, buf, W::R1 * W::R1, lane, wc.w3);
+}
+
+// windowed frame f of (ya [+ i yb]) into buf; TWO = two real signals packed as one complex one
+template <int N, bool TWO>
+__device__ __forceinline__ void wave_load_frame(cplx* buf, const WaveFft<N>& wc, const float* __restrict__ ya,
+                                                const float* __restrict__ yb, const float* __restrict__ window, int p0,
+                                                int T, int lane) {
+  if (p0 >= 0 && p0 + N <= T) {                       // interior frame (wave-uniform): no reflection, 16-byte pieces
+    f4u a[N / 256], c[N / 256], wv[N / 256];
+#pragma unroll
+    for (int i = 0; i < N / 256; ++i) {
+      a[i] = *reinterpret_cast<const f4u*>(ya + p0 + 4 * lane + 256 * i);
+      if (TWO) c[i] = *reinterpret_cast<const f4u*>(yb + p0 + 4 * lane + 256 * i);
+      wv[i] = *reinterpret_cast<const f4u*>(window + 4 * lane + 256 * i);
+    }
+#pragma unroll
+    for (int i = 0; i < N / 256; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float w = wv[i].v[e];
+        buf[fidx<N, 64>(4 * lane + 256 * i + e)] = {w * a[i].v[e], TWO ? w * c[i].v[e] : 0.f};
+      }
+  } else {
+#pragma unroll 4
+    for (int n = lane; n < N; n += 64) {
+      const float w = window[n];
+      const int src = reflect_index(p0 + n, T);
+      buf[fidx<N, 64>(n)] = {w * ya[src], TWO ? w * yb[src] : 0.f};
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// the two real spectra packed in Z at bin k: Y = (Z_k + conj Z_{N-k}) / 2, Yh = (Z_k - conj Z_{N-k}) / 2i
+__device__ __forceinline__ void split_bins(cplx a, cplx c, float& yr, float& yi, float& hr, float& hi) {
+  yr = 0.5f * (a.x + c.x); yi = 0.5f * (a.y - c.y);
+  hr = 0.5f * (a.y + c.y); hi = -0.5f * (a.x - c.x);
+}
+
+template <int N>
+__global__ __launch_bounds__(256, WAVE_LB) void stft_loss_fwd_wave_kernel(const float* __restrict__ y, const float* __restrict__ yh,
+                                                                 const int* __restrict__ lens,
+                                                                 const float* __restrict__ window,
+                                                                 const cplx* __restrict__ tw, float* __restrict__ part,
+                                                                 int T, int hop, int pad, int frames) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int wave = threadIdx.x >> 6, b = blockIdx.y;
+  int lane = threadIdx.x & 63;
+  cplx* Z = reinterpret_cast<cplx*>(smem_raw) + (size_t)wave * frame_padded<N>();
+  WaveFft<N> wc;
+  wc.load(tw, lane);
+  const int len = lens ? lens[b] : T;
+  const float* yb = y + (long long)b * T;
+  const float* hb = yh + (long long)b * T;
+  const int f = blockIdx.x * 4 + wave;      // one frame per wave (a frame LOOP makes the optimiser hoist the twiddle powers
+  if (f < frames) {                         // and every LDS address out of it as invariants: 0.5-1.6 KB of spills per lane)
+    float s_lin = 0.f, s_log = 0.f;
+    if ((N / 2 - pad + f * hop) < len) {          // frame kept iff the sample under its centre tap is unmasked
+        wave_load_frame<N, true>(Z, wc, yb, hb, window, f * hop - pad, T, lane);
+      wave_fft<N, false>(Z, wc, lane);
+      auto bin = [&](int k) {
+        const cplx a = Z[fidx<N, 64>(k)], c = Z[fidx<N, 64>((N - k) & (N - 1))];
+        float yr, yi, hr, hi;
+        split_bins(a, c, yr, yi, hr, hi);
+        const float my = sqrtf(yr * yr + yi * yi), mh = sqrtf(hr * hr + hi * hi);
+        const float d = my - mh;
+        const float dl = __logf(fmaxf(my, 1e-5f)) - __logf(fmaxf(mh, 1e-5f));
+        s_lin = fmaf(d, d, s_lin);
+        s_log = fmaf(dl, dl, s_log);
+      };
+#pragma unroll 4
+      for (int i = 0; i < N / 128; ++i) bin(lane + 64 * i);
+      if (lane == 0) bin(N / 2);
+      __builtin_amdgcn_wave_barrier();             // the next frame's loads overwrite Z
+    }
+    s_lin = wave_sum(s_lin);
+    s_log = wave_sum(s_log);
+    if (lane == 0) {
+      float* o = part + ((long long)b * frames + f) * 2;
+      o[0] = s_lin; o[1] = s_log;
+    }
+  }
+}
+
+template <int N>
+__global__ __launch_bounds__(256, WAVE_LB) void stft_loss_bwd_wave_kernel(const float* __restrict__ y, const float* __restrict__ yh,
+                                                                 const int* __restrict__ lens,
+                                                                 const float* __restrict__ window,
+                                                                 const cplx* __restrict__ tw, const float* __restrict__ coef,
+                                                                 float* __restrict__ rows, int T, int hop, int pad,
+                                                                 int frames) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int wave = threadIdx.x >> 6, b = blockIdx.y;
+  int lane = threadIdx.x & 63;
+  cplx* Z = reinterpret_cast<cplx*>(smem_raw) + (size_t)wave * frame_padded<N>();
+  WaveFft<N> wc;
+  wc.load(tw, lane);
+  const int len = lens ? lens[b] : T;
+  const float* yb = y + (long long)b * T;
+  const float* hb = yh + (long long)b * T;
+  const float c_lin = 2.f * coef[2 * b], c_log = 2.f * coef[2 * b + 1];
+  const int f = blockIdx.x * 4 + wave;
+  if (f < frames && (N / 2 - pad + f * hop) < len) {  // masked frame: no gradient; the gather skips its row
+    wave_load_frame<N, true>(Z, wc, yb, hb, window, f * hop - pad, T, lane);
+    wave_fft<N, false>(Z, wc, lane);
+    // one-sided gradient spectrum IN PLACE: bin k and its mirror N - k are read and rewritten by the same lane in the same
+    // step, and no later step (larger k) reads a slot an earlier one wrote (those are < k or > N - k)
+    auto bin = [&](int k) {
+      const int km = (N - k) & (N - 1);
+      const cplx a = Z[fidx<N, 64>(k)], c = Z[fidx<N, 64>(km)];
+      float yr, yi, hr, hi;
+      split_bins(a, c, yr, yi, hr, hi);
+      const float my = sqrtf(yr * yr + yi * yi), mh = sqrtf(hr * hr + hi * hi);
+      float dmag = -c_lin * (my - mh);
+      if (mh > 1e-5f) dmag -= c_log * (__logf(fmaxf(my, 1e-5f)) - __logf(mh)) / mh;
+      const float inv = mh > 0.f ? dmag / mh : 0.f;
+      if (km != k) Z[fidx<N, 64>(km)] = {0.f, 0.f};
+      Z[fidx<N, 64>(k)] = {inv * hr, inv * hi};
+    };
+#pragma unroll 2
+    for (int i = 0; i < N / 128; ++i) bin(lane + 64 * i);
+    if (lane == 0) bin(N / 2);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    wave_fft<N, true>(Z, wc, lane);                   // x_grad[n] = w[n] Re(sum_k G_k e^{+2 pi i k n / N})
+    float* row = rows + ((long long)b * frames + f) * N;
+#pragma unroll
+    for (int i = 0; i < N / 256; ++i) {
+      const float4 w = *reinterpret_cast<const float4*>(window + 4 * lane + 256 * i);
+      float4 o;
+      o.x = w.x * Z[fidx<N, 64>(4 * lane + 256 * i)].x;
+      o.y = w.y * Z[fidx<N, 64>(4 * lane + 256 * i + 1)].x;
+      o.z = w.z * Z[fidx<N, 64>(4 * lane + 256 * i + 2)].x;
+      o.w = w.w * Z[fidx<N, 64>(4 * lane + 256 * i + 3)].x;
+      *reinterpret_cast<float4*>(row + 4 * lane + 256 * i) = o;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+  }
+}
+
+template <int N>
+__global__ __launch_bounds__(256, WAVE_LB) void melspec_wave_kernel(const float* __restrict__ x, const float* __restrict__ window,
+                                                           const cplx* __restrict__ tw, const float* __restrict__ basis,
+                                                           const int* __restrict__ band, float* __restrict__ mel, int T,
+                                                           int hop, int pad, int frames, int n_mels) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int wave = threadIdx.x >> 6, b = blockIdx.y;
+  int lane = threadIdx.x & 63;
+  constexpr int SLOTS = frame_padded<N>() + N / 2;    // N floats behind the frame for the magnitudes
+  cplx* Z = reinterpret_cast<cplx*>(smem_raw) + (size_t)wave * SLOTS;
+  float* magn = reinterpret_cast<float*>(Z + frame_padded<N>());
+  WaveFft<N> wc;
+  wc.load(tw, lane);
+  const float* xb = x + (long long)b * T;
+  const int f = blockIdx.x * 4 + wave;
+  if (f < frames) {
+    wave_load_frame<N, false>(Z, wc, xb, xb, window, f * hop - pad, T, lane);
+    wave_fft<N, false>(Z, wc, lane);
+#pragma unroll 4
+    for (int i = 0; i < N / 128; ++i) {
+      const cplx z = Z[fidx<N, 64>(lane + 64 * i)];
+      magn[lane + 64 * i] = sqrtf(z.x * z.x + z.y * z.y);
+    }
+    if (lane == 0) { const cplx z = Z[fidx<N, 64>(N / 2)]; magn[N / 2] = sqrtf(z.x * z.x + z.y * z.y); }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    for (int m = lane; m < n_mels; m += 64) {
+      float s = 0.f;
+      const float* row = basis + (long long)m * (N / 2 + 1);
+      const int lo = band[2 * m], hi = band[2 * m + 1];
+      for (int k = lo; k < hi; k += 8) {
+        float w[8], v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int kk = min(k + u, hi - 1);
+          w[u] = row[kk];
+          v[u] = magn[kk];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s = fmaf(k + u < hi ? w[u] : 0.f, v[u], s);
+      }
+      mel[((long long)b * n_mels + m) * frames + f] = logf(fmaxf(s, 1e-5f));
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+  }
+}
+
+// test hook: the one-wave transform alone on one complex frame (tests/test_spectral_gpu.py)
+template <int N>
+__global__ __launch_bounds__(64) void fft_selftest_kernel(const cplx* __restrict__ in, const cplx* __restrict__ tw,
+                                                          cplx* __restrict__ out, int inverse) {
+  __shared__ cplx Z[frame_padded<N>()];
+  int lane = threadIdx.x;
+  WaveFft<N> wc;
+  wc.load(tw, lane);
+  for (int n = lane; n < N; n += 64) Z[fidx<N, 64>(n)] = in[n];
+  wave_fence();
+  if (inverse) wave_fft<N, true>(Z, wc, lane); else wave_fft<N, false>(Z, wc, lane);
+  for (int n = lane; n < N; n += 64) out[n] = Z[fidx<N, 64>(n)];
 }
 
 }  // namespace smt
@@ -508,6 +836,32 @@ static void frame_launch(K kernel, int slots, int nt, int frames, int batch, hip
   kernel<<<dim3((frames + fpw - 1) / fpw, batch), 256, lds, stream>>>(args...);
 }
 
+#if SMT_FFT_STAMP
+extern "C" int smt_fft_debug_dump(unsigned long long* host, int reset) {      // host: [8192][8]
+  int rc = (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fft_dbg), sizeof(unsigned long long) * FFT_DBG_WAVES * 8);
+  if (reset) { static unsigned long long z[FFT_DBG_WAVES * 8]; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(fft_dbg), z, sizeof(z)); }
+  return rc;
+}
+#endif
+
+// launch of a one-wave-per-frame kernel: four frames per workgroup
+template <typename K, typename... Args>
+static void wave_launch(K kernel, int slots, int frames, int batch, hipStream_t stream, Args... args) {
+  const size_t lds = (size_t)4 * slots * sizeof(cplx);
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  kernel<<<dim3((frames + 3) / 4, batch), 256, lds, stream>>>(args...);
+}
+#define SMT_WAVE_DISPATCH(NFFT, CALL)                                       \
+  switch (NFFT) {                                                           \
+    case 256: { constexpr int N = 256; CALL; } break;                       \
+    case 512: { constexpr int N = 512; CALL; } break;                       \
+    case 1024: { constexpr int N = 1024; CALL; } break;                     \
+    case 2048: { constexpr int N = 2048; CALL; } break;                     \
+    default:                                                                \
+      set_error("stft: n_fft=%d unsupported (256, 512, 1024, 2048)", NFFT); \
+      return 1;                                                             \
+  }
+
 static int stft_frames(int T, int n_fft, int hop) { return (T + 2 * ((n_fft - hop) / 2) - n_fft) / hop + 1; }
 
 extern "C" int smt_stft_num_frames(int t, int n_fft, int hop) { return stft_frames(t, n_fft, hop); }
@@ -535,8 +889,13 @@ extern "C" int smt_stft_loss_fwd(const float* y, const float* yh, const int* len
   SMT_CHECK_ARG(t > pad, "smt_stft_loss_fwd: signal shorter than the reflect padding");
   const int frames = stft_frames(t, n_fft, hop);
   if (batch == 0 || frames <= 0) return 0;
-  SMT_FFT_DISPATCH(n_fft, (frame_launch(stft_loss_fwd_kernel<N, NT>, frame_slots<N, NT>(0), NT, frames, batch, stream, y, yh, lens, window, (const cplx*)twiddle,
-                                        partial, t, hop, pad, frames)));
+  if (fft_nt() == 64) {
+    SMT_WAVE_DISPATCH(n_fft, (wave_launch(stft_loss_fwd_wave_kernel<N>, frame_padded<N>(), frames, batch, stream, y, yh, lens, window,
+                                          (const cplx*)twiddle, partial, t, hop, pad, frames)));
+  } else {
+    SMT_FFT_DISPATCH(n_fft, (frame_launch(stft_loss_fwd_kernel<N, NT>, frame_slots<N, NT>(0), NT, frames, batch, stream, y, yh, lens, window, (const cplx*)twiddle,
+                                          partial, t, hop, pad, frames)));
+  }
   SMT_CHECK_LAUNCH("stft_loss_fwd");
   return 0;
 }
@@ -559,8 +918,13 @@ extern "C" int smt_stft_loss_bwd(const float* y, const float* yh, const int* len
   SMT_CHECK_ARG(workspace && workspace_bytes >= smt_stft_loss_bwd_workspace_bytes(batch, t, n_fft, hop),
                 "smt_stft_loss_bwd: workspace too small");
   float* rows = (float*)workspace;
-  SMT_FFT_DISPATCH(n_fft, (frame_launch(stft_loss_bwd_kernel<N, NT>, frame_slots<N, NT>(0), NT, frames, batch, stream, y, yh, lens, window, (const cplx*)twiddle,
-                                        coef, rows, t, hop, pad, frames)));
+  if (fft_nt() == 64) {
+    SMT_WAVE_DISPATCH(n_fft, (wave_launch(stft_loss_bwd_wave_kernel<N>, frame_padded<N>(), frames, batch, stream, y, yh, lens, window,
+                                          (const cplx*)twiddle, coef, rows, t, hop, pad, frames)));
+  } else {
+    SMT_FFT_DISPATCH(n_fft, (frame_launch(stft_loss_bwd_kernel<N, NT>, frame_slots<N, NT>(0), NT, frames, batch, stream, y, yh, lens, window, (const cplx*)twiddle,
+                                          coef, rows, t, hop, pad, frames)));
+  }
   SMT_CHECK_LAUNCH("stft_loss_bwd");
   stft_overlap_gather_kernel<<<dim3((t + 255) / 256, batch), 256, 0, stream>>>(rows, lens, dyh, t, n_fft, hop, pad, frames);
   SMT_CHECK_LAUNCH("stft_overlap_gather");
@@ -576,9 +940,22 @@ extern "C" int smt_melspec(const float* x, const float* window, const float* twi
   SMT_CHECK_ARG(t > pad, "smt_melspec: signal shorter than the reflect padding");
   const int frames = stft_frames(t, n_fft, hop);
   if (batch == 0 || frames <= 0) return 0;
-  SMT_FFT_DISPATCH(n_fft, (frame_launch(melspec_kernel<N, NT>, frame_slots<N, NT>(N / 2), NT, frames, batch, stream, x, window, (const cplx*)twiddle, mel_basis, band,
-                                        mel, t, hop, pad, frames, n_mels)));
+  if (fft_nt() == 64) {
+    SMT_WAVE_DISPATCH(n_fft, (wave_launch(melspec_wave_kernel<N>, frame_padded<N>() + N / 2, frames, batch, stream, x, window,
+                                          (const cplx*)twiddle, mel_basis, band, mel, t, hop, pad, frames, n_mels)));
+  } else {
+    SMT_FFT_DISPATCH(n_fft, (frame_launch(melspec_kernel<N, NT>, frame_slots<N, NT>(N / 2), NT, frames, batch, stream, x, window, (const cplx*)twiddle, mel_basis, band,
+                                          mel, t, hop, pad, frames, n_mels)));
+  }
   SMT_CHECK_LAUNCH("melspec");
+  return 0;
+}
+
+extern "C" int smt_fft_selftest(const float* in, const float* twiddle, float* out, int n_fft, int inverse, smt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SMT_CHECK_ARG(in && twiddle && out, "smt_fft_selftest: null pointer");
+  SMT_WAVE_DISPATCH(n_fft, (fft_selftest_kernel<N><<<1, 64, 0, stream>>>((const cplx*)in, (const cplx*)twiddle, (cplx*)out, inverse)));
+  SMT_CHECK_LAUNCH("fft_selftest");
   return 0;
 }
 

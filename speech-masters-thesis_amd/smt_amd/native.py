@@ -75,6 +75,7 @@ _SIGNATURES = {
     "smt_stft_loss_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int,
                                   c_ptr, c_size, c_ptr]),
     "smt_stft_inverse": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr]),
+    "smt_fft_selftest": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr]),
     "smt_conv_out_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr,
                                  c_size, c_ptr]),
     "smt_lm_make_keys": (c_int, [c_ptr, c_ptr, c_int, c_ptr]),

@@ -136,3 +136,52 @@ def test_stft_inverse_round_trip_at_clip_length():
     assert y.shape[-1] == (spec.shape[-1] - 1) * hop + n_fft - 2 * pad
     n = min(y.shape[-1], t)
     assert (y[:, n_fft:n - n_fft] - x[:, n_fft:n - n_fft]).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("n_fft", [256, 512, 1024, 2048])
+@pytest.mark.parametrize("inverse", [0, 1])
+def test_one_wave_fft_core_matches_a_double_precision_fft(n_fft, inverse):
+    """The in-LDS transform of the frame kernels alone (smt_fft_selftest): radix-16/8 Stockham passes in place, one twiddle
+    load per pass with the others as its powers -- within 1e-6 of torch's float64 FFT relative to the largest bin."""
+    from smt_amd import native as N, spectral
+    g = torch.Generator(device="cuda").manual_seed(n_fft + inverse)
+    x = torch.randn(n_fft, 2, device="cuda", generator=g)
+    _, tw = spectral._get_tables(n_fft, n_fft, x.device)
+    out = torch.empty_like(x)
+    N.check(N.lib().smt_fft_selftest(N.ptr(x), N.ptr(tw), N.ptr(out), n_fft, inverse, N.stream_ptr()), "smt_fft_selftest")
+    xc = torch.view_as_complex(x.double().cpu())
+    ref = torch.fft.ifft(xc) * n_fft if inverse else torch.fft.fft(xc)
+    err = (torch.view_as_complex(out.double().cpu()) - ref).abs().max() / ref.abs().max()
+    assert float(err) < 1e-6
+
+
+@pytest.mark.parametrize("n_fft,hop,win", [(2048, 240, 1200), (1024, 120, 600), (512, 50, 240), (256, 64, 256)])
+def test_one_wave_spectral_kernels_agree_with_the_whole_workgroup_form(n_fft, hop, win):
+    """Two implementations of the same kernels (SMT_FFT_NT=256 selects the round-2 one) on ragged clips whose frames cover
+    both the reflected edges and the 16-byte interior loads: loss 1e-6, gradient 1e-5 relative L2."""
+    import os
+    import subprocess
+    import sys
+    code = f"""
+import sys, torch
+sys.path.insert(0, {os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "speech-masters-thesis_amd")!r})
+from smt_amd import spectral
+g = torch.Generator().manual_seed(0)
+y = (torch.randn(3, 9001, generator=g) * 0.1).cuda()
+yh = (y.cpu() + 0.05 * torch.randn(3, 9001, generator=g)).cuda().requires_grad_(True)
+lens = torch.tensor([9001, 4500, 3000]).cuda()
+l = spectral.stft_loss(y, yh, lens, {n_fft}, {hop}, {win}, True)
+gr, = torch.autograd.grad(l, yh)
+torch.save((l.cpu(), gr.cpu()), sys.argv[1])
+"""
+    import tempfile
+    res = []
+    with tempfile.TemporaryDirectory() as d:
+        for nt in ("64", "256"):
+            path = os.path.join(d, nt + ".pt")
+            env = dict(os.environ, SMT_FFT_NT=nt)
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=env)
+            res.append(torch.load(path, weights_only=True))
+    (l0, g0), (l1, g1) = res
+    assert torch.isfinite(l0) and abs(float(l0 - l1)) <= 1e-6 * abs(float(l1))
+    assert float((g0 - g1).double().norm() / g1.double().norm()) < 1e-5

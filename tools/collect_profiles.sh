@@ -31,4 +31,9 @@ python $R/bench.py --workload transformer_lm --lm_graph --steps 30 --warmup 5 --
 python $R/bench.py --workload transformer_lm --lm_graph --lm_tune_gemm --steps 30 --warmup 5 --no_cpu_baseline > $O/lm_bench_graph_tuned.json 2> $O/lm_bench_graph_tuned.err
 echo "[7/7] auxiliary paths (encode-only pass, STFT.inverse, maximum_path)"; date
 python $R/bench.py --workload aux --steps 10 --warmup 3 > $O/aux_bench.json 2> $O/aux_bench.err
-ls $O $O/stats $O/lm_stats
+echo "[8/8] GlowTTS workload: bench line + kernel stats; spectral kernels stand-alone"; date
+python $R/bench.py --workload glow_tts --steps 10 --warmup 3 > $O/glow_bench.json 2> $O/glow_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/glow_stats -o glow -- python $R/bench.py --workload glow_tts --steps 5 --warmup 2 --no_cpu_baseline --no_kernel_events > $O/glow_stats_bench.json 2> $O/glow_stats_bench.err
+rm -f $O/glow_stats/*kernel_trace.csv
+python $R/tools/bench_spectral.py > $O/spectral_micro.txt 2>&1
+ls $O $O/stats $O/lm_stats $O/glow_stats

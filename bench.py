@@ -869,6 +869,12 @@ def main(argv=None):
                 extra_rooflines[key]["min_us"], extra_rooflines[key]["max_us"] = rec["min_us"], rec["max_us"]
         if world == 1 and not args.no_micro:
             line["rooflines_other"]["melspec"] = melspec_roofline(args, pool[0][4], device, note)
+            mel_traffic = pmc.get("melspec", {}).get("hbm_bytes_per_launch")
+            if mel_traffic is not None:
+                line["rooflines_other"]["melspec"].update(traffic=mel_traffic, traffic_source=pmc_source)
+            st_traffic = pmc.get("stft_loss", {}).get("hbm_bytes_per_launch")
+            if st_traffic is not None and "stft_loss" in line["rooflines_other"]:
+                line["rooflines_other"]["stft_loss"].update(traffic=st_traffic, traffic_source=pmc_source)
             line["vq_micro"] = vq_micro(device, note)
         if world == 1 and not args.no_ragged:
             def factory(rpool):

@@ -27,8 +27,8 @@ GROUPS = [  # (key, substrings of the kernel name)
     ("resample", ["conv4s2_kernel", "convt4s2_kernel"]),
     ("gate_mix_bwd", ["gate_mix_bwd_kernel"]),
     ("conv_gate_bwd", ["conv_gate_bwd_kernel"]),
-    ("melspec", ["melspec_kernel"]),
-    ("stft_loss", ["stft_loss_fwd", "stft_loss_bwd", "stft_loss_gather"]),
+    ("melspec", ["melspec_kernel", "melspec_wave_kernel"]),
+    ("stft_loss", ["stft_loss_fwd", "stft_loss_bwd", "stft_loss_gather", "stft_overlap_gather"]),
     ("vq_ema_accumulate", ["vq_ema_accumulate", "vq_ema_sort", "vq_ema_segment"]),
 ]
 

@@ -673,13 +673,6 @@ __global__ __launch_bounds__(DMA_NT) void conv1x1_dma_kernel(ConvArgs p, const _
 // are not stored -- the hardware's range check replaces the per-lane bounds tests and zero-page selects, and a per-lane
 // 32-bit offset replaces the 64-bit address arithmetic (both were VALU work serial with the MFMAs: tools/ws_phases.py
 // measured 1,100-2,000 cycles per tile for the issue of ~5 DMA instructions per wave).
-typedef int i32x4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t ws_rsrc(const void* base, long long byte_off, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base)) + byte_off, 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ void ws_dma16(__amdgpu_buffer_rsrc_t rs, unsigned voff, void* lds_wave_base) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, 0, 0, 0);
-}
 typedef short s16x2v __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2v __attribute__((ext_vector_type(2)));
 // relu on a packed bf16 pair: a negative bf16 is a negative int16 (v_pk_max_i16)

@@ -19,6 +19,11 @@
 // swz(r) = ((r & 3) << 2) | ((r >> 2) & 3): 16 consecutive rows hit 16 different chunks (row fragments, b128) and
 // 4 consecutive rows are 64 B apart (transposed fragments, 4 rows x 32 B per 16-lane group).
 // Each workgroup leaves its partial dW / db in a slab; conv_wgrad_reduce_kernel sums the slabs in fixed order.
+//
+// Round 3: the tile loop owns its vector-memory waits (see conv_k3gate.hip): tiles and stores go through range-checked
+// V#s (always issued), lens[b] is a scalar load, and ONE counted wait per tile -- vmcnt(4 stores) -- leaves the dx stores
+// draining under the next tile while the prefetched tile is known to have landed.  Before, the vector load of lens[b]
+// made the compiler wait vmcnt(0) right after the prefetch was issued: every tile waited for its own prefetch.
 #include <algorithm>
 
 #include "conv_common.h"
@@ -46,7 +51,7 @@ __device__ __forceinline__ bf16x8 fb_tr2(const unsigned char* pa, const unsigned
   return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(FB_NT) void conv1x1_bwd_kernel(Bwd1x1Args p, const __bf16* __restrict__ zero_page) {
+__global__ __launch_bounds__(FB_NT) void conv1x1_bwd_kernel(Bwd1x1Args p) {
   typedef __bf16 T;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // 2 x [dy tile | u tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -78,21 +83,26 @@ __global__ __launch_bounds__(FB_NT) void conv1x1_bwd_kernel(Bwd1x1Args p, const 
 #pragma unroll
     for (int e = 0; e < 16; ++e) { accw[j][e] = 0.f; accb[j][e] = 0.f; }
 
+  auto decode = [&](int tile, int& b, int& t0) {           // scalars: the V#s below must live in SGPRs
+    b = __builtin_amdgcn_readfirstlane(tile / p.tiles_per_batch);
+    t0 = __builtin_amdgcn_readfirstlane((tile - b * p.tiles_per_batch) * FB_ROWS);
+  };
+  const unsigned pitch_dy = (unsigned)p.lddy * 2u, pitch_u = (unsigned)p.ldu * 2u, pitch_dx = (unsigned)p.lddx * 2u;
+  // group g = wave + 8 q covers rows 4 g + (lane >> 4) = 4 wave + (lane >> 4) + 32 q: fb_swz(row) does not depend on q
+  const int srow = 4 * wave + (lane >> 4);
+  const unsigned schunk = (unsigned)(((lane & 15) ^ fb_swz(srow)) << 4);
   auto stage = [&](int tile, int buf) {
-    const int b = tile / p.tiles_per_batch;
-    const int t0 = (tile - b * p.tiles_per_batch) * FB_ROWS;
-    const T* dyg = reinterpret_cast<const T*>(p.dy) + (long long)b * p.dy_bs;
-    const T* ug = reinterpret_cast<const T*>(p.u) + (long long)b * p.u_bs;
-    unsigned char* base = smem + (size_t)buf * 2 * FB_TILE;
+    int b, t0;
+    decode(tile, b, t0);
+    const UntrackedRsrc rdy = untracked_rsrc(p.dy, (long long)b * p.dy_bs * 2, (unsigned)p.T * pitch_dy);
+    const UntrackedRsrc ru = untracked_rsrc(p.u, (long long)b * p.u_bs * 2, (unsigned)p.T * pitch_u);
+    unsigned char* base = smem + (size_t)buf * 2 * FB_TILE + wave * 1024;
+    unsigned vdy = (unsigned)(t0 + srow) * pitch_dy + schunk, vu = (unsigned)(t0 + srow) * pitch_u + schunk;
 #pragma unroll
-    for (int q = 0; q < (FB_ROWS / 4) / (FB_NT / 64); ++q) {
-      const int g = wave + (FB_NT / 64) * q;
-      const int row = 4 * g + (lane >> 4), pos = lane & 15;
-      const int t = t0 + row;
-      const int chunk = pos ^ fb_swz(row);
-      const bool ok = t < p.T;
-      lds_dma16(ok ? dyg + (long long)t * p.lddy + chunk * 8 : zero_page + pos * 8, base + g * 1024);
-      lds_dma16(ok ? ug + (long long)t * p.ldu + chunk * 8 : zero_page + pos * 8, base + FB_TILE + g * 1024);
+    for (int q = 0; q < (FB_ROWS / 4) / (FB_NT / 64); ++q) {       // rows >= T: out of range, read as zero
+      untracked_dma16(rdy, vdy, base + q * (FB_NT / 64) * 1024);
+      untracked_dma16(ru, vu, base + FB_TILE + q * (FB_NT / 64) * 1024);
+      vdy += 32u * pitch_dy; vu += 32u * pitch_u;
     }
   };
 
@@ -108,12 +118,13 @@ __global__ __launch_bounds__(FB_NT) void conv1x1_bwd_kernel(Bwd1x1Args p, const 
   const int swz_r = fb_swz(r);                                   // rows 64 wm + 32 i + r share it
 
   if (tile_begin < tile_end) stage(tile_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the first tile (and the weights); later tiles: counted wait at the END
   for (int tile = tile_begin; tile < tile_end; ++tile) {
     const int buf = (tile - tile_begin) & 1;
-    const int b = tile / p.tiles_per_batch;
-    const int t0 = (tile - b * p.tiles_per_batch) * FB_ROWS;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile has landed
-    __syncthreads();                                    // ... for every wave; the other buffer is free again
+    int b, t0;
+    decode(tile, b, t0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // every wave's part of this tile landed; the other buffer is free again
     if (tile + 1 < tile_end) stage(tile + 1, buf ^ 1);
     const unsigned char* dyt = smem + (size_t)buf * 2 * FB_TILE;
     const unsigned char* ut = dyt + FB_TILE;
@@ -134,8 +145,8 @@ __global__ __launch_bounds__(FB_NT) void conv1x1_bwd_kernel(Bwd1x1Args p, const 
       }
     }
     {
-      T* dxg = reinterpret_cast<T*>(p.dx) + (long long)b * p.dx_bs;
-      const int len_out = p.lens_out ? p.lens_out[b] : 0x7fffffff;
+      const __amdgpu_buffer_rsrc_t rdx = ws_rsrc(p.dx, (long long)b * p.dx_bs * 2, (unsigned)p.T * pitch_dx);
+      const int len_out = p.lens_out ? scalar_load_i32(p.lens_out + b) : 0x7fffffff;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int row = wm * 64 + 32 * i + r;
@@ -163,11 +174,10 @@ __global__ __launch_bounds__(FB_NT) void conv1x1_bwd_kernel(Bwd1x1Args p, const 
             auto sw = __builtin_amdgcn_permlane32_swap(yp[4 * h2 + d], yp[4 * h2 + 2 + d], false, false);
             yp[4 * h2 + d] = sw[0]; yp[4 * h2 + 2 + d] = sw[1];
           }
-        if (t < p.T) {
-          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-          T* dst = dxg + (long long)t * p.lddx + wn * 32 + 8 * hh;
-          *reinterpret_cast<u32x4*>(dst) = u32x4{yp[0], yp[1], yp[2], yp[3]};
-          *reinterpret_cast<u32x4*>(dst + 16) = u32x4{yp[4], yp[5], yp[6], yp[7]};
+        {                                               // rows >= T: out of range, dropped -- but ISSUED (the wait below counts them)
+          const unsigned vo = (unsigned)t * pitch_dx + (unsigned)(wn * 32 + 8 * hh) * 2u;
+          __builtin_amdgcn_raw_buffer_store_b128(i32x4v{(int)yp[0], (int)yp[1], (int)yp[2], (int)yp[3]}, rdx, (int)vo, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(i32x4v{(int)yp[4], (int)yp[5], (int)yp[6], (int)yp[7]}, rdx, (int)(vo + 32u), 0, 0);
         }
       }
     }
@@ -184,6 +194,9 @@ __global__ __launch_bounds__(FB_NT) void conv1x1_bwd_kernel(Bwd1x1Args p, const 
         if (p.with_bias && wn == 0) accb[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, ones, accb[j], 0, 0, 0);
       }
     }
+    // the next tile's 8 DMA instructions were issued before this tile's 4 dx stores: all but those stores are done
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   }
 
   // ---- partial dW / db of this workgroup -> slab[wg][blk = wm][plane][64][128]
@@ -244,7 +257,7 @@ extern "C" int smt_conv1x1_bwd(const smt_conv_desc* d, float* dweight, int64_t s
     a.with_bias = dbias ? 1 : 0;
     a.scale = d->drop_scale;
     (void)hipFuncSetAttribute((const void*)conv1x1_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    conv1x1_bwd_kernel<<<nwg, FB_NT, 4 * FB_TILE, stream>>>(a, (const __bf16*)d->zero_page);
+    conv1x1_bwd_kernel<<<nwg, FB_NT, 4 * FB_TILE, stream>>>(a);
     SMT_CHECK_LAUNCH("conv1x1_bwd");
   }
   const int jmap[1] = {0};

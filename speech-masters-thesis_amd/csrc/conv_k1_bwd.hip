@@ -17,6 +17,12 @@
 // different chunks for row fragments, 4 consecutive rows 64 B apart for transposed fragments); x rows are 128 B --
 // chunk c of row r at c ^ (((r >> 1) & 3) << 1).
 // Each workgroup leaves its partial dW / db in a slab; conv_wgrad_reduce_kernel sums the slabs in fixed order.
+//
+// Round 3: the tile loop owns its vector-memory waits (see conv_k3gate.hip / conv_common.h).  Vector memory completes in
+// issue order, so everything this tile needs from global memory -- the residual rows -- is issued BEFORE the next tile's
+// prefetch, the prefetch and those loads are untracked (no compiler-placed waits), lens[b] is a scalar load, the two
+// workgroup barriers are raw s_barrier + lgkmcnt(0) (a __syncthreads() also drains vector memory), and the stores stay in
+// flight across the tile boundary: per tile the storing waves wait vmcnt(9) for the residual rows and vmcnt(2) at the end.
 #include <algorithm>
 
 #include "conv_common.h"
@@ -46,7 +52,7 @@ __device__ __forceinline__ bf16x8 kb_tr2(const unsigned char* pa, const unsigned
   return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(KB_NT) void conv_k1_bwd_kernel(K1BwdArgs p, const __bf16* __restrict__ zero_page) {
+__global__ __launch_bounds__(KB_NT) void conv_k1_bwd_kernel(K1BwdArgs p) {
   typedef __bf16 T;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // 2 x [dh tile | x tile], then the reduction scratch
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -58,40 +64,42 @@ __global__ __launch_bounds__(KB_NT) void conv_k1_bwd_kernel(K1BwdArgs p, const _
   const int tile_begin = min(ntiles, wg * p.tiles_per_wg);
   const int tile_end = min(ntiles, tile_begin + p.tiles_per_wg);
 
-  bf16x8 ones;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
-  f32x16 accw[2][2], accb[2];
+  // bias gradient: the dh^T fragment of a lane is 8 rows of ONE output channel, so db is a running sum per lane (round 3;
+  // the MFMA against a constant-one operand it replaces held 32 accumulator + 4 operand registers and the kernel spilled:
+  // a scratch reload inside the tile loop is a tracked load, i.e. an s_waitcnt vmcnt(0) that drains the prefetch)
+  float bsum[2] = {0.f, 0.f};
+  f32x16 accw[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) accb[a][e] = 0.f;
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int e = 0; e < 16; ++e) accw[a][c][e] = 0.f;
   }
 
+  auto decode = [&](int tile, int& b, int& t0) {           // scalars: the V#s below must live in SGPRs
+    b = __builtin_amdgcn_readfirstlane(tile / p.tiles_per_batch);
+    t0 = __builtin_amdgcn_readfirstlane((tile - b * p.tiles_per_batch) * KB_ROWS);
+  };
+  const unsigned pitch_dh = (unsigned)p.lddh * 2u, pitch_x = (unsigned)p.ldx * 2u, pitch_dx = (unsigned)p.lddx * 2u;
+  const int xrow = 8 * wave + (lane >> 3);
+  const unsigned xoff0 = (unsigned)xrow * pitch_x + (unsigned)(((lane & 7) ^ kb_swz_x(xrow)) << 4);
+  constexpr int KB_NDMA = KB_ROWS / (KB_NT / 64) + 1;       // LDS-DMA instructions per wave and tile
   auto stage = [&](int tile, int buf) {
-    const int b = tile / p.tiles_per_batch;
-    const int t0 = (tile - b * p.tiles_per_batch) * KB_ROWS;
-    const T* dhg = reinterpret_cast<const T*>(p.dh) + (long long)b * p.dh_bs;
-    const T* xg = reinterpret_cast<const T*>(p.x) + (long long)b * p.x_bs;
-    const int len = p.lens ? min(p.lens[b], p.T) : p.T;
+    int b, t0;
+    decode(tile, b, t0);
+    const int len = p.lens ? min(scalar_load_i32(p.lens + b), p.T) : p.T;
+    const UntrackedRsrc rdh = untracked_rsrc(p.dh, (long long)b * p.dh_bs * 2, (unsigned)p.T * pitch_dh);
+    const UntrackedRsrc rx = untracked_rsrc(p.x, (long long)b * p.x_bs * 2, (unsigned)len * pitch_x);
     unsigned char* base = smem + (size_t)buf * KB_STAGE;
-#pragma unroll
-    for (int q = 0; q < KB_ROWS / (KB_NT / 64); ++q) {            // dh: one 1 KiB row per instruction
+    int ln = lane;
+    asm volatile("" : "+v"(ln));                                  // the eight swizzled lane offsets are formed here, per tile: hoisted
+#pragma unroll                                                    // out of the tile loop they cost eight registers and the kernel spills
+    for (int q = 0; q < KB_ROWS / (KB_NT / 64); ++q) {            // dh: one 1 KiB row per instruction (rows >= T read as zero)
       const int row = wave + (KB_NT / 64) * q;
-      const int t = t0 + row;
-      const int chunk = lane ^ kb_swz(row);
-      lds_dma16(t < p.T ? dhg + (long long)t * p.lddh + chunk * 8 : zero_page + (lane & 15) * 8, base + row * 1024);
+      untracked_dma16(rdh, (unsigned)(t0 + row) * pitch_dh + (unsigned)((ln ^ kb_swz(row)) << 4), base + row * 1024);
     }
-    {                                                              // x: 8 rows x 8 chunks per instruction
-      const int row = 8 * wave + (lane >> 3), pos = lane & 7;
-      const int t = t0 + row;
-      lds_dma16(t < len ? xg + (long long)t * p.ldx + ((pos ^ kb_swz_x(row)) * 8) : zero_page + pos * 8,
-                base + KB_DH + wave * 1024);
-    }
+    untracked_dma16(rx, xoff0 + (unsigned)t0 * pitch_x, base + KB_DH + wave * 1024);   // x: 8 rows x 8 chunks (rows >= len: zero)
   };
 
   // weight-gradient fragment offsets (the k-step advances rows by 16, which keeps both swizzles)
@@ -116,13 +124,17 @@ __global__ __launch_bounds__(KB_NT) void conv_k1_bwd_kernel(K1BwdArgs p, const _
   float* red = reinterpret_cast<float*>(smem + 2 * KB_STAGE) + (wave & 3) * 1024;   // [16 e][64 lanes] of tile (di, dc)
 
   if (tile_begin < tile_end) stage(tile_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the first tile (and the weights); later tiles: counted waits
+#pragma unroll
+  for (int kk = 0; kk < KB_CO / 32; ++kk) asm volatile("" : "+v"(wfrag[kk]));   // tell the compiler the weight loads are done: it
+                                                       // would otherwise re-wait for them (vmcnt(18) .. vmcnt(3)) inside the loop
   for (int tile = tile_begin; tile < tile_end; ++tile) {
     const int buf = (tile - tile_begin) & 1;
-    const int b = tile / p.tiles_per_batch;
-    const int t0 = (tile - b * p.tiles_per_batch) * KB_ROWS;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile has landed
-    __syncthreads();                                    // ... for every wave; the other buffer is free again
-    if (tile + 1 < tile_end) stage(tile + 1, buf ^ 1);
+    int b, t0;
+    decode(tile, b, t0);
+    const bool more = tile + 1 < tile_end;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // every wave's part of this tile landed; the other buffer is free again
     const unsigned char* base = smem + (size_t)buf * KB_STAGE;
 
     {
@@ -138,20 +150,36 @@ __global__ __launch_bounds__(KB_NT) void conv_k1_bwd_kernel(K1BwdArgs p, const _
         const bf16x8 bv = *reinterpret_cast<const bf16x8*>(base + row * 1024 + (((2 * (kk + 16 * kh) + hh) ^ swz_r) << 4));
         accd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[kk], bv, accd, 0, 0, 0);
       }
+      // residual rows of THIS tile (waves 0..3: channels 32 dc + 8 g + 4 hh + 0..3 of row 32 di + r), THEN the prefetch:
+      // vector memory completes in issue order, so what this tile still needs must be older than the next tile's DMA.
+      // (Issued here, after the MFMAs, the eight residual registers are not live across them: before them the kernel spills.)
+      unsigned rvw[4][2];
+      if (!kh) {
+        const unsigned char* rbase = reinterpret_cast<const unsigned char*>(p.res) + ((long long)b * p.res_bs) * 2;
+        asm volatile("" : "+s"(rbase));
+        const unsigned ro = (unsigned)min(t, p.T - 1) * (unsigned)p.ldres * 2u + (unsigned)(32 * dc + 4 * hh) * 2u;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) untracked_load8(rbase, ro + 16u * g, rvw[g][0], rvw[g][1]);
+      }
+      if (more) stage(tile + 1, buf ^ 1);
       if (kh) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) red[e * 64 + lane] = accd[e];
       }
-      __syncthreads();                                  // partial tiles of waves 4..7 are in LDS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                     // partial tiles of waves 4..7 are in LDS
       if (!kh) {
-        const int len = p.lens ? p.lens[b] : 0x7fffffff;
+        const int len = p.lens ? scalar_load_i32(p.lens + b) : 0x7fffffff;
         const float keep_row = (t >= len) ? 0.f : 1.f;
-        // residual pieces of this lane: channels 32 dc + 8 g + 4 hh + 0..3
+        // the residual loads are older than the prefetch: all but its KB_NDMA instructions are done
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KB_NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         bf16x4 rv[4];
-        {
-          const T* rg = reinterpret_cast<const T*>(p.res) + (long long)b * p.res_bs + (long long)min(t, p.T - 1) * p.ldres + 32 * dc + 4 * hh;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) rv[g] = *reinterpret_cast<const bf16x4*>(rg + 8 * g);
+        for (int g = 0; g < 4; ++g) {
+          asm volatile("" : "+v"(rvw[g][0]), "+v"(rvw[g][1]));          // values as of AFTER the wait
+          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+          rv[g] = __builtin_bit_cast(bf16x4, u32x2{rvw[g][0], rvw[g][1]});
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) accd[e] += red[e * 64 + lane];      // lower half + upper half, always in this order
@@ -171,11 +199,11 @@ __global__ __launch_bounds__(KB_NT) void conv_k1_bwd_kernel(K1BwdArgs p, const _
             auto sw = __builtin_amdgcn_permlane32_swap(yp[4 * h2 + d], yp[4 * h2 + 2 + d], false, false);
             yp[4 * h2 + d] = sw[0]; yp[4 * h2 + 2 + d] = sw[1];
           }
-        if (t < p.T) {
-          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-          T* dst = reinterpret_cast<T*>(p.dx) + (long long)b * p.dx_bs + (long long)t * p.lddx + 32 * dc + 8 * hh;
-          *reinterpret_cast<u32x4*>(dst) = u32x4{yp[0], yp[1], yp[2], yp[3]};
-          *reinterpret_cast<u32x4*>(dst + 16) = u32x4{yp[4], yp[5], yp[6], yp[7]};
+        {                                               // rows >= T: out of range, dropped -- but ISSUED
+          const __amdgpu_buffer_rsrc_t rdx = ws_rsrc(p.dx, (long long)b * p.dx_bs * 2, (unsigned)p.T * pitch_dx);
+          const unsigned vo = (unsigned)t * pitch_dx + (unsigned)(32 * dc + 8 * hh) * 2u;
+          __builtin_amdgcn_raw_buffer_store_b128(i32x4v{(int)yp[0], (int)yp[1], (int)yp[2], (int)yp[3]}, rdx, (int)vo, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(i32x4v{(int)yp[4], (int)yp[5], (int)yp[6], (int)yp[7]}, rdx, (int)(vo + 32u), 0, 0);
         }
       }
     }
@@ -192,9 +220,20 @@ __global__ __launch_bounds__(KB_NT) void conv_k1_bwd_kernel(K1BwdArgs p, const _
         const bf16x8 afr = kb_tr2(base + ((offa0 + k0 * 16 * 1024) ^ (64 * a)), base + ((offa1 + k0 * 16 * 1024) ^ (64 * a)));
 #pragma unroll
         for (int c = 0; c < 2; ++c) accw[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr[c], accw[a][c], 0, 0, 0);
-        if (p.with_bias) accb[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, ones, accb[a], 0, 0, 0);
+        if (p.with_bias) {
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          const u32x4 aw = __builtin_bit_cast(u32x4, afr);
+          float s8 = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s8 += __uint_as_float(aw[j] << 16) + __uint_as_float(aw[j] & 0xffff0000u);
+          bsum[a] += s8;
+        }
       }
     }
+    // the prefetch is older than this tile's two dx stores (waves 0..3) / is the youngest (waves 4..7)
+    __builtin_amdgcn_sched_barrier(0);
+    if (!kh) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
 
   // ---- partial dW / db of this workgroup -> slab[wg][blk = wave][plane][64 co][64 ci]
@@ -206,8 +245,14 @@ __global__ __launch_bounds__(KB_NT) void conv_k1_bwd_kernel(K1BwdArgs p, const _
       const int row = 32 * a + (e & 3) + 8 * (e >> 2) + 4 * hh;
 #pragma unroll
       for (int c = 0; c < 2; ++c) out[(size_t)row * KB_CI + 32 * c + r] = accw[a][c][e];
-      out[(size_t)(64 + row) * KB_CI + r] = accb[a][e];
     }
+  // db: lane l summed output channel 32 a + (l & 31) over the rows of its k-half; halves added in a fixed order; the
+  // reducer reads column 0 of the bias plane
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const float other = __shfl_xor(bsum[a], 32);
+    if (hh == 0) out[(size_t)(64 + 32 * a + r) * KB_CI] = bsum[a] + other;
+  }
 }
 
 static int k1_bwd_nwg(int batch, int t) {
@@ -245,7 +290,7 @@ extern "C" int smt_conv_k1_bwd(const void* dh, int64_t bs_dh, int ld_dh, const v
     a.tiles_per_wg = (int)((ntiles + nwg - 1) / nwg);
     a.with_bias = dbias ? 1 : 0;
     (void)hipFuncSetAttribute((const void*)conv_k1_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    conv_k1_bwd_kernel<<<nwg, KB_NT, 2 * KB_STAGE + KB_RED, stream>>>(a, (const __bf16*)zero_page);
+    conv_k1_bwd_kernel<<<nwg, KB_NT, 2 * KB_STAGE + KB_RED, stream>>>(a);
     SMT_CHECK_LAUNCH("conv_k1_bwd");
   }
   const int jmap[1] = {0};

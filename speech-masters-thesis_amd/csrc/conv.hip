@@ -1704,7 +1704,6 @@ constexpr int K1_ROWS = 128, K1_NT = 512, K1_X = K1_ROWS * 128, K1_COUT = 512;
 
 __global__ __launch_bounds__(K1_NT) void conv_k1act_kernel(ConvArgs p, const __bf16* __restrict__ zero_page,
                                                            int tiles_per_wg) {
-  typedef __bf16 T;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // 2 x [128 rows][128 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
@@ -1735,34 +1734,49 @@ __global__ __launch_bounds__(K1_NT) void conv_k1act_kernel(ConvArgs p, const __b
     cs[c] = col0 - site * p.site_width;
   }
 
+  // Round 3: the tile loop owns its vector-memory waits (conv_common.h, conv_k3gate.hip): untracked x tiles through a V#,
+  // scalar lens loads, stores through a V# (always issued), and ONE counted wait per tile -- vmcnt(16 stores) -- so the
+  // 128 KiB a workgroup writes per tile drains under the next tile instead of in front of it.
+  auto decode = [&](int tile, int& b, int& t0) {
+    b = __builtin_amdgcn_readfirstlane(tile / p.tiles_per_batch);
+    t0 = __builtin_amdgcn_readfirstlane((tile - b * p.tiles_per_batch) * K1_ROWS);
+  };
+  const unsigned pitch_x = (unsigned)p.ldx * 2u, pitch_u = (unsigned)p.ldya * 2u;
+  const int xrow = 8 * wave + (lane >> 3);                        // group wave + 8 q: rows 8 wave + .. + 64 q, swizzle independent of q
+  const unsigned xoff0 = (unsigned)xrow * pitch_x + (unsigned)(((lane & 7) ^ ((xrow >> 1) & 7)) << 4);
   auto stage = [&](int tile, int buf) {
-    const int b = tile / p.tiles_per_batch;
-    const int t0 = (tile - b * p.tiles_per_batch) * K1_ROWS;
-    const T* xg = reinterpret_cast<const T*>(p.x) + (long long)b * p.x_bs;
-    const int len_in = p.lens_in ? min(p.lens_in[b], p.Tin) : p.Tin;
+    int b, t0;
+    decode(tile, b, t0);
+    const int len_in = p.lens_in ? min(scalar_load_i32(p.lens_in + b), p.Tin) : p.Tin;
+    const UntrackedRsrc rx = untracked_rsrc(p.x, (long long)b * p.x_bs * 2, (unsigned)len_in * pitch_x);
+    unsigned vo = xoff0 + (unsigned)t0 * pitch_x;
 #pragma unroll
-    for (int q = 0; q < (K1_ROWS / 8) / (K1_NT / 64); ++q) {     // 8 rows x 8 chunks per instruction
-      const int g = wave + (K1_NT / 64) * q;
-      const int row = 8 * g + (lane >> 3), pos = lane & 7;
-      const int t = t0 + row;
+    for (int q = 0; q < (K1_ROWS / 8) / (K1_NT / 64); ++q) {     // 8 rows x 8 chunks per instruction; rows >= len_in read as zero
       // 128-byte rows: two rows share a 256-byte bank window, chunk c of row n sits at c ^ ((n >> 1) & 7)
-      lds_dma16(t < len_in ? xg + (long long)t * p.ldx + ((pos ^ ((row >> 1) & 7)) * 8) : zero_page + pos * 8,
-                smem + (size_t)buf * K1_X + g * 1024);
+      untracked_dma16(rx, vo, smem + (size_t)buf * K1_X + (wave + (K1_NT / 64) * q) * 1024);
+      vo += 64u * pitch_x;
     }
   };
 
-  T* ug0 = reinterpret_cast<T*>(p.y_act);
   stage(tile_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the first tile, weights and biases; later tiles: counted wait at the END
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) asm volatile("" : "+v"(wfrag[c][kk]));      // (so that the compiler does not re-wait for them in the loop)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) asm volatile("" : "+v"(bval[c][e]));
+  }
   for (int tile = tile_begin; tile < tile_end; ++tile) {
     const int buf = (tile - tile_begin) & 1;
-    const int b = tile / p.tiles_per_batch;
-    const int t0 = (tile - b * p.tiles_per_batch) * K1_ROWS;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile has landed
-    __syncthreads();                                    // ... for every wave; the other buffer is free again
+    int b, t0;
+    decode(tile, b, t0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // every wave's part of this tile landed; the other buffer is free again
     if (tile + 1 < tile_end) stage(tile + 1, buf ^ 1);
     const unsigned char* xt = smem + (size_t)buf * K1_X;
-    T* ug = ug0 + (long long)b * p.ya_bs;
-    const int len_out = p.lens_out ? p.lens_out[b] : 0x7fffffff;
+    const __amdgpu_buffer_rsrc_t ru = ws_rsrc(p.y_act, (long long)b * p.ya_bs * 2, (unsigned)p.Tout * pitch_u);
+    const int len_out = p.lens_out ? scalar_load_i32(p.lens_out + b) : 0x7fffffff;
 #pragma unroll 1
     for (int i = 0; i < K1_ROWS / 32; ++i) {
       const int row = 32 * i + r;
@@ -1778,7 +1792,8 @@ __global__ __launch_bounds__(K1_NT) void conv_k1act_kernel(ConvArgs p, const __b
         for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[c][kk], bv, acc[c], 0, 0, 0);
       }
       const int t = t0 + row;
-      const float keep_row = (t >= len_out) ? 0.f : 1.f;
+      const float srow = (t >= len_out) ? 0.f : p.drop_scale;       // row mask folded into the dropout scale
+      const unsigned thr_m1 = (unsigned)(p.drop_thresh16 - 1) * 0x10001u;
       // dropout hash input of element pair (g, k): ((rowbase + cs + 8 g + k) >> 1) * C + key.  rowbase, cs, 8 g and k are
       // all even (site_width % 32 == 0), so the shift distributes and the product is linear mod 2^32: ONE quarter-rate
       // multiply per (row, column block) instead of eight, the rest are adds of compile-time multiples of C
@@ -1788,18 +1803,16 @@ __global__ __launch_bounds__(K1_NT) void conv_k1act_kernel(ConvArgs p, const __b
         unsigned up[8];
         const unsigned hbase = (rowhalf + (unsigned)(cs[c] >> 1)) * 0x9E3779B1u + keys[c];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float o[4];
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-          for (int k = 0; k < 4; ++k) o[k] = (float)(T)(acc[c][4 * g + k] + bval[c][4 * g + k]) * keep_row;
-#pragma unroll
-          for (int k = 0; k < 4; k += 2) {
-            const unsigned h = fmix32(hbase + (unsigned)(4 * g + (k >> 1)) * 0x9E3779B1u);
-            const bool k0 = (h & 0xFFFFu) >= p.drop_thresh16, k1 = (h >> 16) >= p.drop_thresh16;
-            up[2 * g + (k >> 1)] = pack_bf16x2((k0 && o[k] > 0.f) ? o[k] * p.drop_scale : 0.f,
-                                               (k1 && o[k + 1] > 0.f) ? o[k + 1] * p.drop_scale : 0.f);
+          for (int j = 0; j < 2; ++j) {
+            // h = bf16(acc + bias), two elements per conversion; u = relu(dropout(h)): scale, round, then ReLU and the keep
+            // mask on the packed pair (same arithmetic, element by element, as the generic epilogue)
+            const unsigned hp = pack_bf16x2(acc[c][4 * g + 2 * j] + bval[c][4 * g + 2 * j], acc[c][4 * g + 2 * j + 1] + bval[c][4 * g + 2 * j + 1]);
+            unsigned w = pk_relu_bf16(pack_bf16x2(__builtin_bit_cast(float, hp << 16) * srow, __builtin_bit_cast(float, hp & 0xffff0000u) * srow));
+            if (p.drop_thresh16) w &= pk_keep_mask(fmix32(hbase + (unsigned)(4 * g + j) * 0x9E3779B1u), thr_m1);
+            up[2 * g + j] = w;
           }
-        }
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
@@ -1807,14 +1820,16 @@ __global__ __launch_bounds__(K1_NT) void conv_k1act_kernel(ConvArgs p, const __b
             auto sw = __builtin_amdgcn_permlane32_swap(up[4 * h2 + d], up[4 * h2 + 2 + d], false, false);
             up[4 * h2 + d] = sw[0]; up[4 * h2 + 2 + d] = sw[1];
           }
-        if (t < p.Tout) {
-          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-          T* dst = ug + (long long)t * p.ldya + wave * 64 + 32 * c + 8 * hh;
-          *reinterpret_cast<u32x4*>(dst) = u32x4{up[0], up[1], up[2], up[3]};
-          *reinterpret_cast<u32x4*>(dst + 16) = u32x4{up[4], up[5], up[6], up[7]};
+        {                                               // rows >= Tout: out of range, dropped -- but ISSUED
+          const unsigned vo = (unsigned)t * pitch_u + (unsigned)(wave * 64 + 32 * c + 8 * hh) * 2u;
+          __builtin_amdgcn_raw_buffer_store_b128(i32x4v{(int)up[0], (int)up[1], (int)up[2], (int)up[3]}, ru, (int)vo, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(i32x4v{(int)up[4], (int)up[5], (int)up[6], (int)up[7]}, ru, (int)(vo + 32u), 0, 0);
         }
       }
     }
+    // the next tile's DMA is older than this tile's 16 stores (4 row groups x 2 channel tiles x 2)
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   }
 }
 

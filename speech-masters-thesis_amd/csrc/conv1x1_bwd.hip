@@ -73,15 +73,17 @@ __global__ __launch_bounds__(FB_NT) void conv1x1_bwd_kernel(Bwd1x1Args p) {
     for (int kk = 0; kk < FB_C / 16; ++kk)
       wfrag[kk] = *reinterpret_cast<const bf16x8*>(wrow + (((2 * kk + hh) ^ (ci & 15)) << 4));
   }
-  bf16x8 ones;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
-  f32x16 accw[2], accb[2];
+  // bias gradient: a dy^T fragment is 8 rows of ONE output channel per lane, so db is a running sum per lane; the four waves
+  // that hold the same fragment (wn = 0..3) take every fourth k-step each and leave their partial sums in columns 0, 32, 64,
+  // 96 of the bias plane (the reducer adds them).  Round 2 ran it as MFMAs against a constant-one operand on the wn = 0
+  // waves only: 1.5 x the matrix work of the other waves on SIMD 0, and every tile ends at a workgroup barrier.
+  float bsum[2] = {0.f, 0.f};
+  f32x16 accw[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { accw[j][e] = 0.f; accb[j][e] = 0.f; }
+    for (int e = 0; e < 16; ++e) accw[j][e] = 0.f;
 
   auto decode = [&](int tile, int& b, int& t0) {           // scalars: the V#s below must live in SGPRs
     b = __builtin_amdgcn_readfirstlane(tile / p.tiles_per_batch);
@@ -129,71 +131,88 @@ __global__ __launch_bounds__(FB_NT) void conv1x1_bwd_kernel(Bwd1x1Args p) {
     const unsigned char* dyt = smem + (size_t)buf * 2 * FB_TILE;
     const unsigned char* ut = dyt + FB_TILE;
 
+    // The two halves of a tile's work only READ the tile, so their order is free per wave.  Waves w and w + 4 share a
+    // SIMD: one runs data gradient -> weight gradient, the other the reverse, so that on every SIMD the LDS-heavy transposed
+    // reads and MFMAs of one overlap the VALU epilogue and stores of the other (in lockstep the phases add up: per tile
+    // ~4.3 k cycles of LDS reads + 3 k of MFMA + 2 k of VALU = the 11.4 k cycles measured).
+    auto data_gradient = [&]() {
     // ---- data gradient, transposed: D^T[ci][row] = sum_co Wt[ci][co] * dy[row][co]
-    f32x16 accd[2];
+      f32x16 accd[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) accd[i][e] = 0.f;
+        for (int e = 0; e < 16; ++e) accd[i][e] = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < FB_C / 16; ++kk) {
+      for (int kk = 0; kk < FB_C / 16; ++kk) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = wm * 64 + 32 * i + r;
-        bf16x8 bv = *reinterpret_cast<const bf16x8*>(dyt + row * FB_ROWB + (((2 * kk + hh) ^ swz_r) << 4));
-        accd[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[kk], bv, accd[i], 0, 0, 0);
-      }
-    }
-    {
-      const __amdgpu_buffer_rsrc_t rdx = ws_rsrc(p.dx, (long long)b * p.dx_bs * 2, (unsigned)p.T * pitch_dx);
-      const int len_out = p.lens_out ? scalar_load_i32(p.lens_out + b) : 0x7fffffff;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = wm * 64 + 32 * i + r;
-        const int t = t0 + row;
-        const float keep_row = (t >= len_out) ? 0.f : 1.f;
-        unsigned yp[8];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          // element 4g + k of this lane = input channel wn*32 + 8g + 4hh + k
-          const bf16x4 uv = *reinterpret_cast<const bf16x4*>(ut + row * FB_ROWB + (((wn * 4 + g) ^ swz_r) << 4) + 8 * hh);
-          float o[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float v = (float)(T)accd[i][4 * g + k];
-            o[k] = (((float)uv[k] != 0.f) ? v * p.scale : 0.f) * keep_row;
-          }
-          yp[2 * g] = pack_bf16x2(o[0], o[1]);
-          yp[2 * g + 1] = pack_bf16x2(o[2], o[3]);
-        }
-        // lanes r / r + 32 hold channels {0-3, 8-11, ..} / {4-7, 12-15, ..} of one row -> 16-byte pieces
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-          for (int d = 0; d < 2; ++d) {
-            auto sw = __builtin_amdgcn_permlane32_swap(yp[4 * h2 + d], yp[4 * h2 + 2 + d], false, false);
-            yp[4 * h2 + d] = sw[0]; yp[4 * h2 + 2 + d] = sw[1];
-          }
-        {                                               // rows >= T: out of range, dropped -- but ISSUED (the wait below counts them)
-          const unsigned vo = (unsigned)t * pitch_dx + (unsigned)(wn * 32 + 8 * hh) * 2u;
-          __builtin_amdgcn_raw_buffer_store_b128(i32x4v{(int)yp[0], (int)yp[1], (int)yp[2], (int)yp[3]}, rdx, (int)vo, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(i32x4v{(int)yp[4], (int)yp[5], (int)yp[6], (int)yp[7]}, rdx, (int)(vo + 32u), 0, 0);
+        for (int i = 0; i < 2; ++i) {
+          const int row = wm * 64 + 32 * i + r;
+          bf16x8 bv = *reinterpret_cast<const bf16x8*>(dyt + row * FB_ROWB + (((2 * kk + hh) ^ swz_r) << 4));
+          accd[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[kk], bv, accd[i], 0, 0, 0);
         }
       }
-    }
+      {
+        const __amdgpu_buffer_rsrc_t rdx = ws_rsrc(p.dx, (long long)b * p.dx_bs * 2, (unsigned)p.T * pitch_dx);
+        const int len_out = p.lens_out ? scalar_load_i32(p.lens_out + b) : 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int row = wm * 64 + 32 * i + r;
+          const int t = t0 + row;
+          const float keep_row = (t >= len_out) ? 0.f : 1.f;
+          unsigned yp[8];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            // element 4g + k of this lane = input channel wn*32 + 8g + 4hh + k
+            const bf16x4 uv = *reinterpret_cast<const bf16x4*>(ut + row * FB_ROWB + (((wn * 4 + g) ^ swz_r) << 4) + 8 * hh);
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float v = (float)(T)accd[i][4 * g + k];
+              o[k] = (((float)uv[k] != 0.f) ? v * p.scale : 0.f) * keep_row;
+            }
+            yp[2 * g] = pack_bf16x2(o[0], o[1]);
+            yp[2 * g + 1] = pack_bf16x2(o[2], o[3]);
+          }
+          // lanes r / r + 32 hold channels {0-3, 8-11, ..} / {4-7, 12-15, ..} of one row -> 16-byte pieces
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+              auto sw = __builtin_amdgcn_permlane32_swap(yp[4 * h2 + d], yp[4 * h2 + 2 + d], false, false);
+              yp[4 * h2 + d] = sw[0]; yp[4 * h2 + 2 + d] = sw[1];
+            }
+          {                                               // rows >= T: out of range, dropped -- but ISSUED (the wait below counts them)
+            const unsigned vo = (unsigned)t * pitch_dx + (unsigned)(wn * 32 + 8 * hh) * 2u;
+            __builtin_amdgcn_raw_buffer_store_b128(i32x4v{(int)yp[0], (int)yp[1], (int)yp[2], (int)yp[3]}, rdx, (int)vo, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(i32x4v{(int)yp[4], (int)yp[5], (int)yp[6], (int)yp[7]}, rdx, (int)(vo + 32u), 0, 0);
+          }
+        }
+      }
 
+    };
+    auto weight_gradient = [&]() {
     // ---- weight gradient: dW[co][ci] += sum_rows dy[row][co] * u[row][ci]  (rows beyond T are zero in LDS)
 #pragma unroll
-    for (int k0 = 0; k0 < FB_ROWS / 16; ++k0) {
-      const int ko = k0 * 16 * FB_ROWB;
-      const bf16x8 bfr = fb_tr2(ut + offb0 + ko, ut + offb1 + ko);
+      for (int k0 = 0; k0 < FB_ROWS / 16; ++k0) {
+        const int ko = k0 * 16 * FB_ROWB;
+        const bf16x8 bfr = fb_tr2(ut + offb0 + ko, ut + offb1 + ko);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const bf16x8 afr = fb_tr2(dyt + ((offa0 + ko) ^ (64 * j)), dyt + ((offa1 + ko) ^ (64 * j)));
-        accw[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, accw[j], 0, 0, 0);
-        if (p.with_bias && wn == 0) accb[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, ones, accb[j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) {
+          const bf16x8 afr = fb_tr2(dyt + ((offa0 + ko) ^ (64 * j)), dyt + ((offa1 + ko) ^ (64 * j)));
+          accw[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, accw[j], 0, 0, 0);
+          if (p.with_bias && (k0 & 3) == wn) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 aw = __builtin_bit_cast(u32x4, afr);
+            float s8 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s8 += __uint_as_float(aw[q] << 16) + __uint_as_float(aw[q] & 0xffff0000u);
+            bsum[j] += s8;
+          }
+        }
       }
-    }
+    };
+    if (wm == 0) { data_gradient(); weight_gradient(); }
+    else { weight_gradient(); data_gradient(); }
     // the next tile's 8 DMA instructions were issued before this tile's 4 dx stores: all but those stores are done
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -207,14 +226,18 @@ __global__ __launch_bounds__(FB_NT) void conv1x1_bwd_kernel(Bwd1x1Args p) {
     for (int e = 0; e < 16; ++e) {
       const int row = 32 * j + (e & 3) + 8 * (e >> 2) + 4 * hh;
       out[(size_t)row * FB_C + wn * 32 + r] = accw[j][e];
-      if (wn == 0) out[(size_t)(64 + row) * FB_C + r] = accb[j][e];
     }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {                         // lane l: output channel 32 j + (l & 31), rows of its k-half
+    const float other = __shfl_xor(bsum[j], 32);
+    if (hh == 0) out[(size_t)(64 + 32 * j + r) * FB_C + 32 * wn] = bsum[j] + other;
+  }
 }
 
 static int bwd1x1_nwg(const smt_conv_desc* d) {
   const long long ntiles = (long long)((d->t_out + FB_ROWS - 1) / FB_ROWS) * d->batch;
   // one workgroup per CU (128 KiB of LDS); at least two tiles per workgroup, whole XCD octets
-  long long nwg = std::min<long long>(256, std::max<long long>(8, (ntiles + 1) / 2));
+  long long nwg = std::min<long long>(256, std::max<long long>(8, (ntiles + fused_min_tpw() - 1) / fused_min_tpw()));
   return (int)((nwg + 7) / 8 * 8);
 }
 
@@ -265,5 +288,5 @@ extern "C" int smt_conv1x1_bwd(const smt_conv_desc* d, float* dweight, int64_t s
   // weight gradient of the FORWARD layer: rows = forward output channels (the channels of dy = desc c_in),
   // columns = forward input channels (the channels of u = desc c_out)
   return launch_wgrad_reduce((const float*)workspace, dweight, dbias, n_chunks, 2, 1, 1, FB_C, FB_C, FB_C, stride_out,
-                             stride_in, 0, jmap, stream);
+                             stride_in, 0, jmap, stream, /*bias_cols=*/4);
 }

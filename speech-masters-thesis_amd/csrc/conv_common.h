@@ -1,5 +1,8 @@
 // Pieces shared by the convolution kernels: element traits, 16-byte vectors, counter-based dropout.
 #pragma once
+#include <algorithm>
+#include <cstdlib>
+
 #include "smt_common.h"
 
 namespace smt {
@@ -107,6 +110,14 @@ __device__ __forceinline__ void untracked_load8(const void* sbase, unsigned voff
 __device__ __forceinline__ int scalar_load_i32(const int* ptr) {
   int v;
   asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ptr) : "memory");
+  return v;
+}
+
+// Tiles a persistent workgroup of the fused backward kernels takes at least (SMT_FUSED_MIN_TPW): every workgroup leaves a
+// partial weight-gradient slab that the reduce kernel reads back, so at the small levels of the model fewer, longer
+// workgroups cost less than the slabs of 256 short ones.
+inline int fused_min_tpw() {
+  static const int v = [] { const char* e = getenv("SMT_FUSED_MIN_TPW"); return e ? std::max(1, atoi(e)) : 2; }();
   return v;
 }
 

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(GB_NT) void conv_gate_bwd_kernel(GateBwdArgs p, con
 
 static int gate_bwd_nwg(int batch, int t) {
   const long long ntiles = (long long)((t + GB_ROWS - 1) / GB_ROWS) * batch;
-  long long nwg = std::min<long long>(512, std::max<long long>(8, (ntiles + 1) / 2));   // two workgroups per CU (64 KiB of LDS)
+  long long nwg = std::min<long long>(512, std::max<long long>(8, (ntiles + fused_min_tpw() - 1) / fused_min_tpw()));   // two workgroups per CU (64 KiB of LDS)
   return (int)((nwg + 7) / 8 * 8);
 }
 

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(KB_NT) void conv_k1_bwd_kernel(K1BwdArgs p) {
 
 static int k1_bwd_nwg(int batch, int t) {
   const long long ntiles = (long long)((t + KB_ROWS - 1) / KB_ROWS) * batch;
-  long long nwg = std::min<long long>(256, std::max<long long>(8, (ntiles + 1) / 2));   // one workgroup per CU (144 KiB of LDS)
+  long long nwg = std::min<long long>(256, std::max<long long>(8, (ntiles + fused_min_tpw() - 1) / fused_min_tpw()));   // one workgroup per CU (144 KiB of LDS)
   return (int)((nwg + 7) / 8 * 8);
 }
 

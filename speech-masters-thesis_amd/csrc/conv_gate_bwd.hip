@@ -69,21 +69,27 @@ __global__ __launch_bounds__(GB_NT) void conv_gate_bwd_kernel(GateBwdArgs p, con
 #pragma unroll
   for (int e = 0; e < 16; ++e) { accw[e] = 0.f; accb[e] = 0.f; }
 
+  // Round 3: the tile loop owns its vector-memory waits (conv_common.h, conv_k3gate.hip): untracked LDS-DMA through V#s,
+  // scalar lens loads, dx stores through a V# (always issued), one counted wait per tile.
+  auto decode = [&](int tile, int& b, int& t0) {
+    b = __builtin_amdgcn_readfirstlane(tile / p.tiles_per_batch);
+    t0 = __builtin_amdgcn_readfirstlane((tile - b * p.tiles_per_batch) * GB_ROWS);
+  };
+  const unsigned pitch_dy = (unsigned)p.lddy * 2u, pitch_g = (unsigned)p.ldg * 2u, pitch_dx = (unsigned)p.lddx * 2u;
   auto stage = [&](int tile, int buf) {
-    const int b = tile / p.tiles_per_batch;
-    const int t0 = (tile - b * p.tiles_per_batch) * GB_ROWS;
-    const T* dyg = reinterpret_cast<const T*>(p.dy) + (long long)b * p.dy_bs;
-    const T* gg = reinterpret_cast<const T*>(p.g) + (long long)b * p.g_bs;
-    const int len = p.lens ? min(p.lens[b], p.T) : p.T;
+    int b, t0;
+    decode(tile, b, t0);
+    const int len = p.lens ? min(scalar_load_i32(p.lens + b), p.T) : p.T;
+    const UntrackedRsrc rdy = untracked_rsrc(p.dy, (long long)b * p.dy_bs * 2, (unsigned)p.T * pitch_dy);
+    const UntrackedRsrc rg = untracked_rsrc(p.g, (long long)b * p.g_bs * 2, (unsigned)len * pitch_g);
     unsigned char* base = smem + (size_t)buf * GB_STAGE;
 #pragma unroll
-    for (int q = 0; q < (GB_ROWS / 8) / (GB_NT / 64); ++q) {      // 8 rows x 8 chunks per instruction
+    for (int q = 0; q < (GB_ROWS / 8) / (GB_NT / 64); ++q) {      // 8 rows x 8 chunks per instruction; rows >= T / >= len read as zero
       const int i8 = wave + (GB_NT / 64) * q;
       const int row = 8 * i8 + (lane >> 3), pos = lane & 7;
-      const int t = t0 + row;
-      const int chunk = pos ^ gb_swz(row);
-      lds_dma16(t < p.T ? dyg + (long long)t * p.lddy + chunk * 8 : zero_page + pos * 8, base + i8 * 1024);
-      lds_dma16(t < len ? gg + (long long)t * p.ldg + chunk * 8 : zero_page + pos * 8, base + GB_TILE + i8 * 1024);
+      const unsigned ch = (unsigned)((pos ^ gb_swz(row)) << 4);
+      untracked_dma16(rdy, (unsigned)(t0 + row) * pitch_dy + ch, base + i8 * 1024);
+      untracked_dma16(rg, (unsigned)(t0 + row) * pitch_g + ch, base + GB_TILE + i8 * 1024);
     }
   };
 
@@ -97,12 +103,15 @@ __global__ __launch_bounds__(GB_NT) void conv_gate_bwd_kernel(GateBwdArgs p, con
   const int offb1 = GB_TILE + rb * 128 + (((col_b >> 3) ^ gb_swz(rb)) << 4) + (col_b & 7) * 2;
 
   if (tile_begin < tile_end) stage(tile_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the first tile (and the weights); later tiles: counted wait at the END
+#pragma unroll
+  for (int kk = 0; kk < GB_C / 16; ++kk) asm volatile("" : "+v"(wfrag[kk]));
   for (int tile = tile_begin; tile < tile_end; ++tile) {
     const int buf = (tile - tile_begin) & 1;
-    const int b = tile / p.tiles_per_batch;
-    const int t0 = (tile - b * p.tiles_per_batch) * GB_ROWS;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile has landed
-    __syncthreads();                                    // ... for every wave; the other buffer is free again
+    int b, t0;
+    decode(tile, b, t0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // every wave's part of this tile landed; the other buffer is free again
     if (tile + 1 < tile_end) stage(tile + 1, buf ^ 1);
     const unsigned char* base = smem + (size_t)buf * GB_STAGE;
 
@@ -110,7 +119,7 @@ __global__ __launch_bounds__(GB_NT) void conv_gate_bwd_kernel(GateBwdArgs p, con
     {
       const int row = 32 * ri + r;
       const int t = t0 + row;
-      const int len = p.lens ? p.lens[b] : 0x7fffffff;
+      const int len = p.lens ? scalar_load_i32(p.lens + b) : 0x7fffffff;
       const float keep_row = (t >= len) ? 0.f : 1.f;
       f32x16 accd;
 #pragma unroll
@@ -137,11 +146,11 @@ __global__ __launch_bounds__(GB_NT) void conv_gate_bwd_kernel(GateBwdArgs p, con
           auto sw = __builtin_amdgcn_permlane32_swap(yp[4 * h2 + d], yp[4 * h2 + 2 + d], false, false);
           yp[4 * h2 + d] = sw[0]; yp[4 * h2 + 2 + d] = sw[1];
         }
-      if (t < p.T) {
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        T* dst = reinterpret_cast<T*>(p.dx) + (long long)b * p.dx_bs + (long long)t * p.lddx + 32 * dc + 8 * hh;
-        *reinterpret_cast<u32x4*>(dst) = u32x4{yp[0], yp[1], yp[2], yp[3]};
-        *reinterpret_cast<u32x4*>(dst + 16) = u32x4{yp[4], yp[5], yp[6], yp[7]};
+      {                                                 // rows >= T: out of range, dropped -- but ISSUED
+        const __amdgpu_buffer_rsrc_t rdx = ws_rsrc(p.dx, (long long)b * p.dx_bs * 2, (unsigned)p.T * pitch_dx);
+        const unsigned vo = (unsigned)t * pitch_dx + (unsigned)(32 * dc + 8 * hh) * 2u;
+        __builtin_amdgcn_raw_buffer_store_b128(i32x4v{(int)yp[0], (int)yp[1], (int)yp[2], (int)yp[3]}, rdx, (int)vo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(i32x4v{(int)yp[4], (int)yp[5], (int)yp[6], (int)yp[7]}, rdx, (int)(vo + 32u), 0, 0);
       }
     }
 
@@ -154,6 +163,9 @@ __global__ __launch_bounds__(GB_NT) void conv_gate_bwd_kernel(GateBwdArgs p, con
       accw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, accw, 0, 0, 0);
       if (p.with_bias && wc == 0) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, ones, accb, 0, 0, 0);
     }
+    // the next tile's DMA was issued before this tile's 2 dx stores
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   }
 
   // ---- partial dW / db -> slab[chunk = 2 wg + kh][plane][64 co][64 ci]

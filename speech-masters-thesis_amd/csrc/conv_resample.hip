@@ -30,7 +30,8 @@ constexpr int RS_NT = 512;
 typedef unsigned rs_u32x4 __attribute__((ext_vector_type(4)));
 
 // pack the 16 accumulator values of a lane (+ bias, row mask) into two 16-byte pieces of 8 consecutive channels each
-__device__ __forceinline__ void rs_store(const f32x16& acc, const float* bval, float keep, __bf16* dst) {
+// (stored through a range-checked V#: rows beyond the output are dropped by the hardware, the instruction is always issued)
+__device__ __forceinline__ void rs_store(const f32x16& acc, const float* bval, float keep, __amdgpu_buffer_rsrc_t ry, unsigned vo) {
   unsigned yp[8];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
@@ -44,11 +45,14 @@ __device__ __forceinline__ void rs_store(const f32x16& acc, const float* bval, f
       auto sw = __builtin_amdgcn_permlane32_swap(yp[4 * h2 + d], yp[4 * h2 + 2 + d], false, false);
       yp[4 * h2 + d] = sw[0]; yp[4 * h2 + 2 + d] = sw[1];
     }
-  if (dst) {
-    *reinterpret_cast<rs_u32x4*>(dst) = rs_u32x4{yp[0], yp[1], yp[2], yp[3]};
-    *reinterpret_cast<rs_u32x4*>(dst + 16) = rs_u32x4{yp[4], yp[5], yp[6], yp[7]};
-  }
+  __builtin_amdgcn_raw_buffer_store_b128(i32x4v{(int)yp[0], (int)yp[1], (int)yp[2], (int)yp[3]}, ry, (int)vo, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(i32x4v{(int)yp[4], (int)yp[5], (int)yp[6], (int)yp[7]}, ry, (int)(vo + 32u), 0, 0);
 }
+
+// Round 3: both tile loops own their vector-memory waits (conv_common.h, conv_k3gate.hip): untracked LDS-DMA through a V#
+// (rows before the item wrap to huge offsets, rows >= len are beyond it: both read as zero), scalar lens loads, one counted
+// wait per tile that leaves the tile's stores in flight.
+#define RS_MARK_LOADED(arr, n) _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) asm volatile("" : "+v"((arr)[i_]))
 
 // ------------------------------------------------------------------------------------------ transposed, C_in = 64
 constexpr int CT_TM = 128;                                   // input rows per tile (256 output rows)
@@ -57,7 +61,6 @@ constexpr int CT_BUF = CT_ROWS * 128;
 
 template <int COUT>
 __global__ __launch_bounds__(RS_NT) void convt4s2_kernel(RsArgs p, const __bf16* __restrict__ zero_page, int tiles_per_wg) {
-  typedef __bf16 T;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // 2 x [136 rows x 128 B]
   constexpr int NCG = COUT / 32;                             // 32-channel groups
   constexpr int NRH = 8 / (2 * NCG);                         // row halves sharing the tile (1 for 128 channels, 2 for 64)
@@ -92,31 +95,40 @@ __global__ __launch_bounds__(RS_NT) void convt4s2_kernel(RsArgs p, const __bf16*
 #pragma unroll
   for (int e = 0; e < 16; ++e) bval[e] = p.bias ? p.bias[cg * 32 + 4 * hh + 8 * (e >> 2) + (e & 3)] : 0.f;
 
+  auto decode = [&](int tile, int& b, int& m0) {
+    b = __builtin_amdgcn_readfirstlane(tile / p.tiles_per_batch);
+    m0 = __builtin_amdgcn_readfirstlane((tile - b * p.tiles_per_batch) * CT_TM);
+  };
+  const unsigned pitch_x = (unsigned)p.ldx * 2u, pitch_y = (unsigned)p.ldy * 2u;
   auto stage = [&](int tile, int buf) {
-    const int b = tile / p.tiles_per_batch;
-    const int m0 = (tile - b * p.tiles_per_batch) * CT_TM;
-    const T* xg = p.x + (long long)b * p.x_bs;
-    const int len = p.lens_in ? min(p.lens_in[b], p.Tin) : p.Tin;
+    int b, m0;
+    decode(tile, b, m0);
+    const int len = p.lens_in ? min(scalar_load_i32(p.lens_in + b), p.Tin) : p.Tin;
+    const UntrackedRsrc rx = untracked_rsrc(p.x, (long long)b * p.x_bs * 2, (unsigned)len * pitch_x);
     unsigned char* base = smem + (size_t)buf * CT_BUF;
-    for (int gi = wave; gi < CT_ROWS / 8; gi += RS_NT / 64) {  // 8 rows x 8 chunks per wave-instruction
-      const int row = 8 * gi + (lane >> 3), pos = lane & 7;
-      const int m = m0 - 1 + row;
-      const bool ok = m >= 0 && m < len;
-      lds_dma16(ok ? xg + (long long)m * p.ldx + ((pos ^ ((row >> 1) & 7)) * 8) : zero_page + pos * 8, base + gi * 1024);
+#pragma unroll
+    for (int q = 0; q < (CT_ROWS / 8 + RS_NT / 64 - 1) / (RS_NT / 64); ++q) {   // 8 rows x 8 chunks per wave-instruction (17 pieces:
+      const int gi = wave + (RS_NT / 64) * q;                                   // the third round is wave 0's alone -- see the wait)
+      if (gi < CT_ROWS / 8) {
+        const int row = 8 * gi + (lane >> 3), pos = lane & 7;
+        untracked_dma16(rx, (unsigned)(m0 - 1 + row) * pitch_x + (unsigned)((pos ^ ((row >> 1) & 7)) << 4), base + gi * 1024);
+      }
     }
   };
 
   stage(tile_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the first tile, weights, biases; later tiles: counted wait at the END
+  RS_MARK_LOADED(wa, 4); RS_MARK_LOADED(wb, 4); RS_MARK_LOADED(bval, 16);
   for (int tile = tile_begin; tile < tile_end; ++tile) {
     const int buf = (tile - tile_begin) & 1;
-    const int b = tile / p.tiles_per_batch;
-    const int m0 = (tile - b * p.tiles_per_batch) * CT_TM;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this tile has landed
-    __syncthreads();                                          // ... for every wave; the other buffer is free again
+    int b, m0;
+    decode(tile, b, m0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                             // every wave's part of this tile landed; the other buffer is free again
     if (tile + 1 < tile_end) stage(tile + 1, buf ^ 1);
     const unsigned char* xt = smem + (size_t)buf * CT_BUF;
-    T* yg = p.y + (long long)b * p.y_bs;
-    const int len_out = p.lens_out ? p.lens_out[b] : 0x7fffffff;
+    const __amdgpu_buffer_rsrc_t ry = ws_rsrc(p.y, (long long)b * p.y_bs * 2, (unsigned)p.Tout * pitch_y);
+    const int len_out = p.lens_out ? scalar_load_i32(p.lens_out + b) : 0x7fffffff;
 #pragma unroll
     for (int i = 0; i < RGW; ++i) {
       const int lm = rb + 32 * i + r;                        // tile row m - m0 of this lane
@@ -135,8 +147,11 @@ __global__ __launch_bounds__(RS_NT) void convt4s2_kernel(RsArgs p, const __bf16*
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[kk], vb, acc, 0, 0, 0);
       }
       const int m = m0 + lm, t = 2 * m + ph;
-      rs_store(acc, bval, t < len_out ? 1.f : 0.f, m < p.Tin ? yg + (long long)t * p.ldy + cg * 32 + 8 * hh : nullptr);
+      rs_store(acc, bval, t < len_out ? 1.f : 0.f, ry, (unsigned)t * pitch_y + (unsigned)(cg * 32 + 8 * hh) * 2u);
     }
+    // the next tile's DMA is older than this tile's 2 RGW stores
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * RGW) : "memory");
   }
 }
 
@@ -145,7 +160,6 @@ constexpr int CS_TO = 128;                                   // output rows per 
 
 template <int CIN>
 __global__ __launch_bounds__(RS_NT) void conv4s2_kernel(RsArgs p, const __bf16* __restrict__ zero_page, int tiles_per_wg) {
-  typedef __bf16 T;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   constexpr int ROWB = CIN * 2;                              // bytes per staged row
   constexpr int RPI = 1024 / ROWB;                           // rows per DMA wave-instruction (8 or 4)
@@ -180,27 +194,38 @@ __global__ __launch_bounds__(RS_NT) void conv4s2_kernel(RsArgs p, const __bf16* 
 
   // chunk c of staged row l sits at c ^ swz(l): consecutive output rows read staged rows 2 apart
   auto swz = [](int l) { return (l >> 1) & (CPR - 1); };
+  auto decode = [&](int tile, int& b, int& t0) {
+    b = __builtin_amdgcn_readfirstlane(tile / p.tiles_per_batch);
+    t0 = __builtin_amdgcn_readfirstlane((tile - b * p.tiles_per_batch) * CS_TO);
+  };
+  const unsigned pitch_x = (unsigned)p.ldx * 2u, pitch_y = (unsigned)p.ldy * 2u;
   auto stage = [&](int tile, int buf) {
-    const int b = tile / p.tiles_per_batch;
-    const int t0 = (tile - b * p.tiles_per_batch) * CS_TO;
-    const T* xg = p.x + (long long)b * p.x_bs;
-    const int len = p.lens_in ? min(p.lens_in[b], p.Tin) : p.Tin;
+    int b, t0;
+    decode(tile, b, t0);
+    const int len = p.lens_in ? min(scalar_load_i32(p.lens_in + b), p.Tin) : p.Tin;
+    const UntrackedRsrc rx = untracked_rsrc(p.x, (long long)b * p.x_bs * 2, (unsigned)len * pitch_x);
     unsigned char* base = smem + (size_t)buf * BUF;
-    for (int gi = wave; gi < ROWS / RPI; gi += RS_NT / 64) {
-      const int row = RPI * gi + lane / CPR, pos = lane % CPR;
-      const int n = 2 * t0 - 1 + row;
-      const bool ok = n >= 0 && n < len;
-      lds_dma16(ok ? xg + (long long)n * p.ldx + ((pos ^ swz(row)) * 8) : zero_page + (pos & 7) * 8, base + gi * 1024);
+#pragma unroll
+    for (int q = 0; q < (ROWS / RPI + RS_NT / 64 - 1) / (RS_NT / 64); ++q) {
+      const int gi = wave + (RS_NT / 64) * q;
+      if (gi < ROWS / RPI) {
+        const int row = RPI * gi + lane / CPR, pos = lane % CPR;
+        untracked_dma16(rx, (unsigned)(2 * t0 - 1 + row) * pitch_x + (unsigned)((pos ^ swz(row)) << 4), base + gi * 1024);
+      }
     }
   };
 
   stage(tile_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the first tile, weights, biases; later tiles: counted wait at the END
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { RS_MARK_LOADED(wf[j], KS); }
+  RS_MARK_LOADED(bval, 16);
   for (int tile = tile_begin; tile < tile_end; ++tile) {
     const int buf = (tile - tile_begin) & 1;
-    const int b = tile / p.tiles_per_batch;
-    const int t0 = (tile - b * p.tiles_per_batch) * CS_TO;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    int b, t0;
+    decode(tile, b, t0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     if (tile + 1 < tile_end) stage(tile + 1, buf ^ 1);
     const unsigned char* xt = smem + (size_t)buf * BUF;
     const int lt = 32 * rg + r;                              // output row of this lane inside the tile
@@ -217,9 +242,12 @@ __global__ __launch_bounds__(RS_NT) void conv4s2_kernel(RsArgs p, const __bf16* 
       }
     }
     const int t = t0 + lt;
-    const int len_out = p.lens_out ? p.lens_out[b] : 0x7fffffff;
-    T* yg = p.y + (long long)b * p.y_bs;
-    rs_store(acc, bval, t < len_out ? 1.f : 0.f, t < p.Tout ? yg + (long long)t * p.ldy + cg * 32 + 8 * hh : nullptr);
+    const int len_out = p.lens_out ? scalar_load_i32(p.lens_out + b) : 0x7fffffff;
+    const __amdgpu_buffer_rsrc_t ry = ws_rsrc(p.y, (long long)b * p.y_bs * 2, (unsigned)p.Tout * pitch_y);
+    rs_store(acc, bval, t < len_out ? 1.f : 0.f, ry, (unsigned)t * pitch_y + (unsigned)(cg * 32 + 8 * hh) * 2u);
+    // the next tile's DMA is older than this tile's 2 stores
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   }
 }
 

@@ -177,7 +177,11 @@ typedef struct smt_conv_desc {
   const void* res; const void* act_grad_src;
   const int* lens_in; const int* lens_out;
   int w_swizzled;                  /* w was packed with swizzle = 1: enables the LDS-DMA kernel */
-  const void* zero_page;           /* >= 256 zero bytes in device memory (source of out-of-range rows), or NULL */
+  const void* zero_page;           /* >= 256 zero bytes in device memory (source of out-of-range rows), or NULL.  Since round 3
+                                    * the fused streaming entries (smt_conv_k3gate_fwd, smt_conv_k1_bwd, smt_conv_gate_bwd,
+                                    * smt_conv1x1_bwd, smt_conv4s2, smt_convt4s2, the K1 activated-output path) address their
+                                    * operands through range-checked buffer descriptors and no longer read it; the argument
+                                    * stays in their signatures (ABI 3) and must still be non-NULL where it was required. */
   /* Optional second 1x1 term folded into the same output (bf16 1x1 LDS-DMA path only, c_in == 128, c_in2 == 64):
    *   y += bias2[co] + sum_ci2 x2[b, t, ci2] * w2[co][ci2]
    * GatedHiFiBlock adds the branch input h1 = K1(x) + b1 to K3's output (resnet.py:226); K1 being linear, the

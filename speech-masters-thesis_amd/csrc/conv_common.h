@@ -85,7 +85,10 @@ __device__ __forceinline__ UntrackedRsrc untracked_rsrc(const void* base, long l
 __device__ __forceinline__ void untracked_dma16(const UntrackedRsrc& rs, unsigned voff, const void* lds_wave_base) {
   const unsigned m0v = __builtin_amdgcn_readfirstlane(
       (int)(unsigned)reinterpret_cast<size_t>((__attribute__((address_space(3))) const void*)lds_wave_base));
-  asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voff), "s"(rs.w), "s"(m0v) : "memory");
+  // Hazards the compiler pads for its own instructions but not inside inline asm: an SALU write of M0 needs one wait state
+  // before an LDS-DMA reads it, and an SGPR written by the VALU (v_readfirstlane: the descriptor words, the LDS address) needs
+  // five before a vector-memory instruction reads it.  s_nop 4 after the M0 write covers both.
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voff), "s"(rs.w), "s"(m0v) : "memory");
 }   // writes M0 (not declarable as a clobber: reserved): do not mix with the ws_dma16 builtin in one kernel
 
 // A 16-byte global load the COMPILER DOES NOT TRACK (scalar base + 32-bit lane offset).  While LDS-DMA is in flight hipcc
@@ -94,14 +97,14 @@ __device__ __forceinline__ void untracked_dma16(const UntrackedRsrc& rs, unsigne
 // caller owns the wait: s_waitcnt vmcnt(N) with N = the vector-memory instructions issued after this one.
 __device__ __forceinline__ i32x4v untracked_load16(const void* sbase, unsigned voff) {
   i32x4v v;
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");   // s_nop: see untracked_dma16
   return v;
 }
 
 __device__ __forceinline__ void untracked_load8(const void* sbase, unsigned voff, unsigned& lo, unsigned& hi) {
   typedef int i32x2v __attribute__((ext_vector_type(2)));
   i32x2v v;
-  asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+  asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
   lo = (unsigned)v[0]; hi = (unsigned)v[1];
 }
 

@@ -809,6 +809,7 @@ def main(argv=None):
                               "hbm", dt, "resample"),
             "conv_k1act": group({"conv_k1act"}, "smt::conv_k1act_kernel (K1, activated output only, HBM-bound)", "hbm",
                                 dt, "conv_k1act_kernel"),
+            "conv1x1_c64": group({"conv1x1_c64"}, "smt::conv1x1_c64_kernel (gate conv forward + residual, HBM-bound)", "hbm", dt),
             "conv_k1_bwd": group({"conv_k1_bwd"}, "smt::conv_k1_bwd_kernel (fused K1 backward, HBM-bound)", "hbm", dt,
                                  "conv_k1_bwd_kernel"),
             "conv_gemm_dma": group({"conv_gemm_dma"}, "smt::conv_gemm_dma_kernel (LDS-DMA streaming kernel, small levels)",

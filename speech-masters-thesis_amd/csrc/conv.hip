@@ -1850,6 +1850,139 @@ static int launch_conv_k1act(ConvArgs p, const void* zero_page, hipStream_t stre
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The gate conv of GatedHiFiBlock, forward (reference models/vqvae/resnet.py:238-241): out = W g + b + x, a 64 -> 64 1 x 1
+// conv with the block input as residual -- 128 B + 128 B in, 128 B out per row.  It ran on the generic register-staged
+// kernel at 4 % of its roofs (1.07 ms/step over the 14 blocks; the bytes allow 0.3).  Same machine as conv_k1act: persistent
+// workgroups (two per CU), the 64 x 64 weight block in registers (wave w: output channels 32 (w & 1).., rows 32 (w >> 1)..),
+// g and x tiles through an untracked LDS-DMA double buffer, transposed MFMA tile, the generic epilogue's arithmetic element
+// by element -- out = bf16(bf16(acc + b) * keep_row + x) -- v_permlane32_swap pairing, 16-byte stores through a V#, one
+// counted wait per tile.
+constexpr int C64_ROWS = 128, C64_NT = 512, C64_TILE = C64_ROWS * 128;
+
+__global__ __launch_bounds__(C64_NT) void conv1x1_c64_kernel(ConvArgs p, int tiles_per_wg) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // 2 x [g tile | x tile], 128 rows x 128 B each
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int ct = wave & 1, rg = wave >> 1;
+
+  const int ntiles = p.tiles_per_batch * p.B;
+  const int nwg = gridDim.x;
+  const int wg = (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3);
+  const int tile_begin = wg * tiles_per_wg;
+  const int tile_end = min(ntiles, tile_begin + tiles_per_wg);
+  if (tile_begin >= tile_end) return;
+
+  bf16x8 wfrag[4];
+  float bval[16];
+  {
+    const int co = 32 * ct + r;
+    const unsigned char* wrow = reinterpret_cast<const unsigned char*>(p.w) + (size_t)co * 128;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) wfrag[kk] = *reinterpret_cast<const bf16x8*>(wrow + ((2 * kk + hh) << 4));
+    // accumulator element 4g + k of a lane = output channel 32 ct + 4 hh + 8g + k
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bval[e] = p.bias ? p.bias[32 * ct + 4 * hh + 8 * (e >> 2) + (e & 3)] : 0.f;
+  }
+
+  auto decode = [&](int tile, int& b, int& t0) {
+    b = __builtin_amdgcn_readfirstlane(tile / p.tiles_per_batch);
+    t0 = __builtin_amdgcn_readfirstlane((tile - b * p.tiles_per_batch) * C64_ROWS);
+  };
+  const unsigned pitch_x = (unsigned)p.ldx * 2u, pitch_r = (unsigned)p.ldr * 2u, pitch_y = (unsigned)p.ldy * 2u;
+  const int srow = 8 * wave + (lane >> 3);                         // group wave + 8 q: rows 8 wave + .. + 64 q
+  const unsigned schunk = (unsigned)(((lane & 7) ^ ((srow >> 1) & 7)) << 4);   // chunk c of row n sits at c ^ ((n >> 1) & 7)
+  auto stage = [&](int tile, int buf) {
+    int b, t0;
+    decode(tile, b, t0);
+    const int len_in = p.lens_in ? min(scalar_load_i32(p.lens_in + b), p.Tin) : p.Tin;
+    const UntrackedRsrc rx = untracked_rsrc(p.x, (long long)b * p.x_bs * 2, (unsigned)len_in * pitch_x);
+    const UntrackedRsrc rr = untracked_rsrc(p.res, (long long)b * p.res_bs * 2, (unsigned)p.Tout * pitch_r);
+    unsigned char* base = smem + (size_t)buf * 2 * C64_TILE + wave * 1024;
+#pragma unroll
+    for (int q = 0; q < (C64_ROWS / 8) / (C64_NT / 64); ++q) {     // 8 rows x 8 chunks per instruction
+      untracked_dma16(rx, (unsigned)(t0 + srow + 64 * q) * pitch_x + schunk, base + q * (C64_NT / 64) * 1024);
+      untracked_dma16(rr, (unsigned)(t0 + srow + 64 * q) * pitch_r + schunk, base + C64_TILE + q * (C64_NT / 64) * 1024);
+    }
+  };
+
+  stage(tile_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the first tile, weights and biases; later tiles: counted wait at the END
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) asm volatile("" : "+v"(wfrag[kk]));
+#pragma unroll
+  for (int e = 0; e < 16; ++e) asm volatile("" : "+v"(bval[e]));
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    const int buf = (tile - tile_begin) & 1;
+    int b, t0;
+    decode(tile, b, t0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // every wave's part of this tile landed; the other buffer is free again
+    if (tile + 1 < tile_end) stage(tile + 1, buf ^ 1);
+    const unsigned char* gt = smem + (size_t)buf * 2 * C64_TILE;
+    const unsigned char* xt = gt + C64_TILE;
+    const __amdgpu_buffer_rsrc_t ry = ws_rsrc(p.y, (long long)b * p.y_bs * 2, (unsigned)p.Tout * pitch_y);
+    const int len_out = p.lens_out ? scalar_load_i32(p.lens_out + b) : 0x7fffffff;
+    const int row = 32 * rg + r;
+    const int swz = (row >> 1) & 7;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const bf16x8 bv = *reinterpret_cast<const bf16x8*>(gt + row * 128 + (((2 * kk + hh) ^ swz) << 4));
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[kk], bv, acc, 0, 0, 0);
+    }
+    const int t = t0 + row;
+    const float keep_row = (t >= len_out) ? 0.f : 1.f;
+    unsigned yp[8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      // residual channels 32 ct + 8 g + 4 hh + 0..3 of this row: half of the 16-byte chunk 4 ct + g
+      const uint2 rv = *reinterpret_cast<const uint2*>(xt + row * 128 + (((4 * ct + g) ^ swz) << 4) + 8 * hh);
+      const unsigned h01 = pack_bf16x2(acc[4 * g] + bval[4 * g], acc[4 * g + 1] + bval[4 * g + 1]);
+      const unsigned h23 = pack_bf16x2(acc[4 * g + 2] + bval[4 * g + 2], acc[4 * g + 3] + bval[4 * g + 3]);
+      yp[2 * g] = pack_bf16x2(fmaf(__builtin_bit_cast(float, h01 << 16), keep_row, __builtin_bit_cast(float, rv.x << 16)),
+                              fmaf(__builtin_bit_cast(float, h01 & 0xffff0000u), keep_row, __builtin_bit_cast(float, rv.x & 0xffff0000u)));
+      yp[2 * g + 1] = pack_bf16x2(fmaf(__builtin_bit_cast(float, h23 << 16), keep_row, __builtin_bit_cast(float, rv.y << 16)),
+                                  fmaf(__builtin_bit_cast(float, h23 & 0xffff0000u), keep_row, __builtin_bit_cast(float, rv.y & 0xffff0000u)));
+    }
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        auto sw = __builtin_amdgcn_permlane32_swap(yp[4 * h2 + d], yp[4 * h2 + 2 + d], false, false);
+        yp[4 * h2 + d] = sw[0]; yp[4 * h2 + 2 + d] = sw[1];
+      }
+    {                                                   // rows >= Tout: out of range, dropped -- but ISSUED
+      const unsigned vo = (unsigned)t * pitch_y + (unsigned)(32 * ct + 8 * hh) * 2u;
+      __builtin_amdgcn_raw_buffer_store_b128(i32x4v{(int)yp[0], (int)yp[1], (int)yp[2], (int)yp[3]}, ry, (int)vo, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(i32x4v{(int)yp[4], (int)yp[5], (int)yp[6], (int)yp[7]}, ry, (int)(vo + 32u), 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");    // the next tile's DMA is older than this tile's two stores
+  }
+}
+
+static bool conv1x1_c64_eligible(const smt_conv_desc* d) {
+  static const bool off = getenv("SMT_NO_C64") != nullptr;
+  return !off && d->dtype == SMT_BF16 && d->taps == 1 && d->c_in == 64 && d->c_out == 64 && d->stride == 1 && d->out_stride == 1 &&
+         d->out_offset == 0 && d->t_y == d->t_out && d->t_in == d->t_out && d->y && d->res && !d->act_out && !d->act_grad &&
+         !d->x2 && !d->w_swizzled && d->zero_page && d->ld_x % 8 == 0 && d->ld_res % 8 == 0 && d->ld_y % 8 == 0;
+}
+
+static int launch_conv1x1_c64(ConvArgs p, hipStream_t stream) {
+  p.tiles_per_batch = (p.Tout + C64_ROWS - 1) / C64_ROWS;
+  const int ntiles = p.tiles_per_batch * p.B;
+  int nwg = std::min(512, std::max(8, (ntiles + 1) / 2));     // two workgroups per CU (64 KiB of LDS each)
+  nwg = (nwg + 7) / 8 * 8;
+  const int tpw = (ntiles + nwg - 1) / nwg;
+  (void)hipFuncSetAttribute((const void*)conv1x1_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * C64_TILE);
+  conv1x1_c64_kernel<<<nwg, C64_NT, 4 * C64_TILE, stream>>>(p, tpw);
+  SMT_CHECK_LAUNCH("conv1x1_c64");
+  return 0;
+}
+
 static int launch_conv1x1_dma(ConvArgs p, const void* zero_page, hipStream_t stream) {
   p.tiles_per_batch = (p.Tout + DMA_BM - 1) / DMA_BM;
   const int ntiles = p.tiles_per_batch * p.B;
@@ -2082,7 +2215,7 @@ static void conv_args_from_desc(const smt_conv_desc* d, ConvArgs& p) {
   { static int dbg = getenv("SMT_CONV_DBG") ? atoi(getenv("SMT_CONV_DBG")) : 0; p.dbg = dbg; }
 }
 
-enum ConvKernelKind { K_GENERIC, K_1X1, K_DMA, K_WS, K_FOLD, K_K1ACT };
+enum ConvKernelKind { K_GENERIC, K_1X1, K_DMA, K_WS, K_FOLD, K_K1ACT, K_C64 };
 static bool conv_fold_eligible(const smt_conv_desc* d) {
   return d->x2 && d->w2 && d->c_in2 == 64 && d->taps == 1 && d->c_in == 128 && !d->res && !d->act_grad && !d->act_out &&
          d->y && d->ld_x2 % 8 == 0;
@@ -2090,6 +2223,7 @@ static bool conv_fold_eligible(const smt_conv_desc* d) {
 // the one dispatch rule (smt_conv1d_ntc and smt_conv1d_kernel_name both use it)
 static ConvKernelKind pick_kernel(const smt_conv_desc* d, const ConvArgs& p0) {
   if (conv_k1act_eligible(d)) return K_K1ACT;
+  if (conv1x1_c64_eligible(d)) return K_C64;
   if (!conv_dma_eligible(d)) return K_GENERIC;
   if (d->x2) return conv_fold_eligible(d) ? K_FOLD : K_GENERIC;
   if (d->taps == 1 && d->c_in == 128) return K_1X1;
@@ -2138,6 +2272,7 @@ extern "C" int smt_conv1d_ntc(const smt_conv_desc* d, smt_stream_t stream_) {
   switch (kind) {
     case K_FOLD: return launch_conv1x1_fold(p, d->zero_page, stream);
     case K_K1ACT: return launch_conv_k1act(p, d->zero_page, stream);
+    case K_C64: return launch_conv1x1_c64(p, stream);
     case K_1X1: return launch_conv1x1_dma(p, d->zero_page, stream);
     case K_DMA: case K_WS: return launch_conv_dma(p, d->zero_page, stream);
     default: break;
@@ -2155,6 +2290,7 @@ extern "C" const char* smt_conv1d_kernel_name(const smt_conv_desc* d) {
     case K_1X1: return "conv1x1_dma";
     case K_FOLD: return "conv1x1_fold";
     case K_K1ACT: return "conv_k1act";
+    case K_C64: return "conv1x1_c64";
     case K_WS: {  // same rule as launch_ws: two waves per SIMD for <= 5 taps; else the pipelined variant for the activated-output epilogue
       const bool fwd = !d->y && d->act_out && !d->res && !d->act_grad, dgrad = d->y && !d->act_out && d->res && d->act_grad;
       if (d->taps <= WS2_MAX_TAPS && (fwd || dgrad) && !getenv("SMT_CONV_NO_WS2")) return "conv_ws2";

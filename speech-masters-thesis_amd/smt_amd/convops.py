@@ -925,6 +925,7 @@ class _GatedHiFi(torch.autograd.Function):
         dg_ = _base_desc(g, out, lens32, w, w, 1, 1, 1, 0, t)
         dg_.w, dg_.bias = _p(_pack_fwd(wg, dt)), _p(bg)
         dg_.res, dg_.bs_res, dg_.ld_res = _geom(x)
+        dg_.zero_page = _p(_zero_page(x.device))   # opts into the streaming kernels (conv1x1_c64 at width 64)
         _launch(dg_, "conv_fwd", _conv_flops(dg_), _conv_bytes(dg_, x.element_size()))
 
         ctx.save_for_backward(x, lens32 if lens32 is not None else torch.empty(0), u1, u2, z, g, *params)

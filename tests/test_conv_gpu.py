@@ -457,6 +457,37 @@ def test_k1_activated_output_kernel_matches_generic_kernel(b, t, train):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("b,t", [(3, 700), (2, 20011), (1, 1), (2, 128)])
+def test_gate_conv_forward_kernel_matches_generic_kernel(b, t):
+    """conv1x1_c64 (the 64 -> 64 gate conv with the block input as residual, out = W g + b + x) against the generic kernel on
+    the same inputs: bit-identical, ragged lens and channel-sliced (pitch 256) operands included."""
+    from smt_amd import convops as C
+    g = torch.Generator(device="cuda").manual_seed(17 * b + t)
+    big = torch.randn(b, t, 128, device="cuda", generator=g).to(torch.bfloat16)
+    x = big[:, :, 64:128]                                          # channel slice: row pitch 128 elements
+    res = torch.randn(b, t, 64, device="cuda", generator=g).to(torch.bfloat16)
+    w = torch.randn(64, 64, 1, device="cuda", generator=g) / 8.0
+    bias = torch.randn(64, device="cuda", generator=g)
+    lens = torch.tensor([t, max(1, t // 3), 1][:b], device="cuda", dtype=torch.int32)
+    wp = C._pack_fwd(w, torch.bfloat16)
+    outs, names = [], []
+    for fast in (False, True):
+        y = torch.full((b, t, 64), 7.0, device="cuda", dtype=torch.bfloat16)
+        d = C._base_desc(x, y, lens, 64, 64, 1, 1, 1, 0, t)
+        d.w, d.bias = C._p(wp), C._p(bias)
+        d.res, d.bs_res, d.ld_res = C._geom(res)
+        if fast:
+            d.zero_page = C._p(C._zero_page(x.device))
+        names.append(C._kernel_of(d))
+        C._launch(d, "t")
+        torch.cuda.synchronize()
+        outs.append(y)
+    assert names == ["conv_gemm", "conv1x1_c64"]
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[1][0, lens[0]:], res[0, lens[0]:]) or int(lens[0]) == t   # rows beyond lens: the residual alone
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("b,t", [(3, 700), (2, 20011), (1, 1)])
 def test_fused_k1_backward_matches_separate_kernels(b, t):
     """smt_conv_k1_bwd (one pass over dh) against the data-gradient conv it replaces (within one bf16 rounding step,

@@ -48,7 +48,7 @@ def kernel_names():
 # ------------------------------------------------------------------------------------------------------------
 # (a) block level
 # ------------------------------------------------------------------------------------------------------------
-FAST_FWD = {"conv_k1act:fwd", "conv_ws_pipe:fwd", "conv_ws2:fwd", "conv_k3gate"}
+FAST_FWD = {"conv_k1act:fwd", "conv_ws_pipe:fwd", "conv_ws2:fwd", "conv_k3gate", "conv1x1_c64:fwd"}
 FAST_BWD = {"conv_gate_bwd", "gate_mix_bwd", "conv1x1_bwd", "conv_ws:dgrad", "conv_ws2:dgrad", "conv_wgrad_shift", "conv_k1_bwd"}
 
 

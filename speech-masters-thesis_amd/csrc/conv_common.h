@@ -128,7 +128,8 @@ inline int fused_min_tpw() {
 // [plane = tap | bias][64 co][cib ci] -> dw[co*so + ci*si + jmap[tap]*sj], db[co] (column 0 of the bias plane).
 int launch_wgrad_reduce(const float* slab, float* dw, float* db, int n_chunks, int nblk_co, int nblk_ci, int taps,
                         int c_in, int c_out, int cib, long long so, long long si, long long sj, const int* jmap,
-                        hipStream_t stream, int bias_cols = 1);   // bias_cols > 1: db = sum of columns 0, 32, .. of the bias plane
+                        hipStream_t stream, int bias_cols = 1,    // bias_cols > 1: db = sum of columns 0, 32, .. of the bias plane
+                        int vsplit = 0);                          // vsplit > 0: slab column ci = channel ci % vsplit of tap ci / vsplit
 
 
 }  // namespace smt

@@ -30,6 +30,8 @@ struct WgradArgs {
   int taps, stride, dil, pad, out_stride, out_offset;
   int rows_per_chunk, chunks_per_batch, nblk_ci, nblk_co, with_bias;
   int rs;   // dilation-class row stride (LDS-DMA kernel), 1 = off
+  int win, xstride;   // window mode (LDS-DMA kernel): the Cin "channels" of output row t are the 64-channel rows
+                      // xstride t - pad, xstride t - pad + 1, .. of x side by side (Cin / 64 taps of a 64-channel conv)
 };
 
 // R = rows per staged tile; CIB = input channels per workgroup (CIB/32 wave columns, 2 wave rows);
@@ -292,26 +294,31 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(WgradArgs p, const 
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
+  // Round 3: untracked LDS-DMA through range-checked V#s (conv_common.h): the compiler used to put a wait for the NEXT tile's
+  // prefetch in front of the first transposed read of the current tile, so nothing overlapped (it mattered little while the
+  // kernel only ran 5- and 9-tap layers with 40+ MFMAs per tile; in window mode a tile is 8-16 MFMAs).  An offset of ~0 is
+  // out of range of any descriptor: such lanes read zero (rows past the chunk, before the item, past the valid length).
+  const UntrackedRsrc rdy = untracked_rsrc(dyg + co0, 0, (unsigned)min((long long)0xfffffff0ll, (long long)Tc * ldy * 2));
+  const UntrackedRsrc rxx = untracked_rsrc(xg + (p.win ? 0 : ci0), 0, (unsigned)min((long long)0xfffffff0ll, (long long)len_in * ldx * 2));
+  const unsigned pdy = (unsigned)(ldy * 2), pxx = (unsigned)(ldx * 2);
   auto stage = [&](int t0, int buf) {
     unsigned char* base = smem + (size_t)buf * buf_bytes;
     // dy: 128 rows x 8 chunks; one wave-instruction = 8 rows
     for (int g = wave; g < R / 8; g += NTHR / 64) {
       const int row = 8 * g + (lane >> 3), pos = lane & 7;
       const int t = t0 + row;
-      const bool ok = t < t_end;
       const int ch = pos ^ (((row >> 1) & 1) << 2);
-      const T* src = ok ? dyg + (long long)t * ldy + co0 + ch * 8 : zero_page + pos * 8;
-      wg_dma16(src, base + g * 1024);
+      untracked_dma16(rdy, t < t_end ? (unsigned)t * pdy + (unsigned)(ch << 4) : 0xffffff00u, base + g * 1024);
     }
     // x: rows_x_pad rows x 16 chunks; one wave-instruction = 4 rows
     const int tin0 = t0 - p.pad;
     for (int g = wave; g < rows_x_pad / 4; g += NTHR / 64) {
       const int row = 4 * g + (lane >> 4), pos = lane & 15;
-      const int tin = tin0 + row;
-      const bool ok = (row < rows_x) && (tin >= 0) && (tin < len_in);
       const int ch = pos ^ ((row & 3) << 2);
-      const T* src = ok ? xg + (long long)tin * ldx + ci0 + ch * 8 : zero_page + pos * 8;
-      wg_dma16(src, base + DY_BYTES + g * 1024);
+      int tin = tin0 + row, cch = ch;                     // input row and 16-byte chunk inside the 128-channel block
+      if (p.win) { cch = (ci0 >> 3) + ch; tin = p.xstride * (t0 + row) - p.pad + (cch >> 3); cch &= 7; }
+      const bool ok = (row < rows_x) && (tin >= 0) && (tin < len_in);
+      untracked_dma16(rxx, ok ? (unsigned)tin * pxx + (unsigned)(cch << 4) : 0xffffff00u, base + DY_BYTES + g * 1024);
     }
   };
 
@@ -340,13 +347,23 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(WgradArgs p, const 
     return __builtin_bit_cast(bf16x8, v);
   };
 
+  // Window mode runs THREE stage buffers (3 x 48 KiB): a tile is 8-16 MFMAs per wave, far shorter than the 2-3 us a tile takes
+  // to arrive, so one tile of prefetch leaves the kernel waiting on latency (measured: 176 us per launch = 36 tiles x 2.5 us x
+  // two rounds of workgroups).  Its DMA count per wave and tile is a constant (2 dy + 4 x pieces), so the counted wait can leave
+  // the newest tile in flight.  The other modes keep two buffers (their tile size varies with taps and dilation).
+  const int nbuf = p.win ? 3 : 2;
   stage(t_begin, 0);
+  if (p.win && t_begin + R < t_end) { stage(t_begin + R, 1); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   int it = 0;
   for (int t0 = t_begin; t0 < t_end; t0 += R, ++it) {
-    const int buf = it & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                       // tile `it` has landed for every wave; the other buffer is free
-    if (t0 + R < t_end && !((WABL & 1) && it > 0)) stage(t0 + R, buf ^ 1);
+    const int buf = it % nbuf;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // tile `it` has landed for every wave (each waited at the end of the previous
+                                           // iteration); the buffer read in the previous iteration is free
+    const int ahead = nbuf - 1;
+    const bool more = t0 + ahead * R < t_end && !((WABL & 1) && it > 0);
+    if (more) stage(t0 + ahead * R, (it + ahead) % nbuf);
     const unsigned char* dyt = smem + (size_t)buf * buf_bytes + dyoff;
     const unsigned char* xbase = smem + (size_t)buf * buf_bytes + DY_BYTES;
     bf16x8 a0, b0;
@@ -365,6 +382,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(WgradArgs p, const 
         }
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    // the next tile must have landed; in window mode the one after it (6 instructions per wave) may still be in flight
+    if (p.win && more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   const int planes = ntaps + 1;
   float* out = p.slab + ((size_t)cgl * nblk + blk) * (size_t)planes * CB * CIB;
@@ -580,6 +601,7 @@ struct WreduceJob {
   const float* slab; float* dw; float* db;
   long long so, si, sj;
   int n_chunks, nblk, nblk_ci, planes, taps, Cin, Cout, cib, bias_cols;
+  int vsplit;                      // > 0: window mode -- column ci of the slab is input channel ci % vsplit of tap ci / vsplit
   int block0;                      // first workgroup of this job inside the launch
   int wblocks;                     // workgroups of the weight part (the bias part follows)
   signed char jmap[16];
@@ -630,7 +652,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(WreduceBatch bt)
       f32x4 t = part[0][o];
 #pragma unroll
       for (int k = 1; k < 8; ++k) t += part[k][o];
-      float* dst = p.dw + co * p.so + ci * p.si + p.jmap[plane] * p.sj;
+      float* dst = p.vsplit > 0 ? p.dw + co * p.so + (ci % p.vsplit) * p.si + p.jmap[ci / p.vsplit] * p.sj
+                                : p.dw + co * p.so + ci * p.si + p.jmap[plane] * p.sj;
       dst[0] = t[0]; dst[p.si] = t[1]; dst[2 * p.si] = t[2]; dst[3 * p.si] = t[3];
     }
   } else {
@@ -711,7 +734,7 @@ static int reduce_flush(hipStream_t stream) {
 
 int launch_wgrad_reduce(const float* slab, float* dw, float* db, int n_chunks, int nblk_co, int nblk_ci, int taps,
                         int c_in, int c_out, int cib, long long so, long long si, long long sj, const int* jmap,
-                        hipStream_t stream, int bias_cols) {
+                        hipStream_t stream, int bias_cols, int vsplit) {
   SMT_CHECK_ARG(c_in % 4 == 0 && cib % 4 == 0 && taps <= 16, "conv_wgrad_reduce: c_in and the ci block must be multiples of 4");
   if (g_reduce_batch.n_jobs == WR_MAXJ) {
     int rc = reduce_flush(stream);
@@ -719,11 +742,13 @@ int launch_wgrad_reduce(const float* slab, float* dw, float* db, int n_chunks, i
   }
   WreduceJob& r = g_reduce_batch.job[g_reduce_batch.n_jobs];
   r.bias_cols = bias_cols;
+  r.vsplit = vsplit;
   r.slab = slab; r.dw = dw; r.db = db;
   r.n_chunks = n_chunks; r.nblk = nblk_co * nblk_ci; r.nblk_ci = nblk_ci; r.planes = taps + 1; r.taps = taps;
   r.Cin = c_in; r.Cout = c_out; r.cib = cib;
   r.so = so; r.si = si; r.sj = sj;
-  for (int t = 0; t < 16; ++t) r.jmap[t] = (signed char)(t < taps ? jmap[t] : 0);
+  const int n_map = vsplit > 0 ? c_in / vsplit : taps;      // window mode: one entry per real tap
+  for (int t = 0; t < 16; ++t) r.jmap[t] = (signed char)(t < n_map ? jmap[t] : 0);
   const long long total4 = (long long)taps * c_out * (c_in / 4);
   r.wblocks = (int)((total4 + 31) / 32);
   r.block0 = g_reduce_batch.total_blocks;
@@ -743,6 +768,8 @@ extern "C" int smt_wgrad_reduce_defer(int on, smt_stream_t stream_) {
   g_reduce_defer = on != 0;
   return on ? 0 : reduce_flush((hipStream_t)stream_);
 }
+
+static bool wgrad_window_desc(const smt_conv_desc* d, smt_conv_desc* v);
 
 static size_t wgrad_group_ws(const smt_conv_desc* d) {
   int rpc, cpb, nco, nci, planes;
@@ -766,6 +793,8 @@ extern "C" size_t smt_conv1d_wgrad_workspace_bytes(const smt_conv_desc* d) {
   ShiftPlan pl;
   if (wgrad_shift_plan(d, &pl))
     best = (size_t)pl.n_chunks * pl.nblk_co * pl.nblk_ci * (d->taps + 1) * 64 * 128 * sizeof(float);
+  smt_conv_desc wv;
+  if (wgrad_window_desc(d, &wv)) return std::max(best, align_up(wgrad_group_ws(&wv), 256));
   // tap groups get consecutive regions (their reductions may be deferred: smt_wgrad_reduce_defer)
   size_t groups = 0;
   for (int j0 = 0; j0 < d->taps; j0 += WG_GROUP) {
@@ -815,7 +844,7 @@ static int wgrad_group(const smt_conv_desc* d, float* dweight, int64_t stride_ou
   a.out_stride = d->out_stride; a.out_offset = d->out_offset;
   a.rows_per_chunk = rpc; a.chunks_per_batch = cpb; a.nblk_ci = nci; a.nblk_co = nco; a.with_bias = dbias ? 1 : 0;
   const int rs = wgrad_rs(d);
-  a.rs = rs;
+  a.rs = rs; a.win = 0; a.xstride = 1;
   if (rs > 1) { a.pad = d->padding / rs; a.dil = 1; }
   if (d->batch > 0 && d->t_out > 0) {
     const int n_chunks = d->batch * rs * cpb;
@@ -860,10 +889,61 @@ static int wgrad_group(const smt_conv_desc* d, float* dweight, int64_t stride_ou
                              cib, stride_out, stride_in, stride_tap, tap_map, stream);
 }
 
+// Window mode of the LDS-DMA kernel (round 3): the weight gradients of the k = 4 / stride-2 resampling convs of a
+// 64-channel level and of the two-tap phases of their transposes.  dW[co][ci][j] = sum_t dy[t][co] x[s t - pad + j][ci] is a
+// 1 x 1 weight gradient over 64 * taps "virtual" channels whose 64-wide groups are consecutive ROWS of x; the kernel gathers
+// them chunk by chunk while staging, the reducer scatters virtual columns back to (ci, tap).  MEASURED SLOWER than the
+// register-staged generic kernel on the layers it was built for (k2/out_stride 2, 64 -> 128: 221 vs 176 us per launch;
+// 64 -> 64: 89 vs 73; k4/stride 2: 138 vs 116 -- both forms already move their bytes at 5-6 TB/s: each phase of a transpose
+// re-reads x, each 64-channel output block re-reads it again), so it is OFF unless SMT_WGRAD_WINDOW=1 (read per call).
+static bool wgrad_window_desc(const smt_conv_desc* d, smt_conv_desc* v) {
+  const char* env = getenv("SMT_WGRAD_WINDOW");
+  const bool off = !env || atoi(env) == 0;
+  const bool shape = (d->stride == 2 && d->taps == 4 && d->out_stride == 1 && d->out_offset == 0) ||
+                     (d->stride == 1 && d->taps == 2 && d->out_stride >= 1);
+  if (off || d->dtype != SMT_BF16 || d->c_in != 64 || d->c_out % 64 != 0 || !d->zero_page || d->dilation != 1 || !shape ||
+      d->ld_x % 8 != 0 || d->ld_y % 8 != 0 || d->t_out < 1)
+    return false;
+  *v = *d;
+  v->c_in = 64 * d->taps; v->taps = 1; v->stride = 1; v->dilation = 1; v->padding = 0;
+  v->out_stride = 1; v->out_offset = 0;                   // folded into the dy pointer and pitch by the launcher
+  return true;
+}
+
+static int wgrad_window(const smt_conv_desc* d, const smt_conv_desc* v, float* dweight, int64_t stride_out, int64_t stride_in,
+                        int64_t stride_tap, const int* tap_map, float* dbias, void* workspace, size_t workspace_bytes,
+                        hipStream_t stream) {
+  SMT_CHECK_ARG(d->x && d->y && dweight && workspace, "smt_conv1d_wgrad: null pointer");
+  SMT_CHECK_ARG(workspace_bytes >= wgrad_group_ws(v), "smt_conv1d_wgrad: workspace too small");
+  SMT_CHECK_ARG((long long)(d->t_out - 1) * d->out_stride + d->out_offset < d->t_y, "smt_conv1d_wgrad: output rows out of range");
+  int rpc, cpb, nco, nci, planes;
+  wgrad_plan(v, &rpc, &cpb, &nco, &nci, &planes);
+  WgradArgs a;
+  a.x = d->x; a.slab = (float*)workspace; a.lens_in = d->lens_in;
+  a.dy = reinterpret_cast<const __bf16*>(d->y) + (long long)d->out_offset * d->ld_y;
+  a.x_bs = d->bs_x; a.dy_bs = d->bs_y; a.ldx = d->ld_x; a.ldy = d->ld_y * d->out_stride;
+  a.B = d->batch; a.Tin = d->t_in; a.Tout = d->t_out; a.Ty = d->t_y; a.Cin = v->c_in; a.Cout = d->c_out;
+  a.taps = 1; a.stride = 1; a.dil = 1; a.pad = d->padding; a.out_stride = 1; a.out_offset = 0;
+  a.rows_per_chunk = rpc; a.chunks_per_batch = cpb; a.nblk_ci = nci; a.nblk_co = nco; a.with_bias = dbias ? 1 : 0;
+  a.rs = 1; a.win = 1; a.xstride = d->stride;
+  const int n_chunks = d->batch * cpb;
+  if (d->batch > 0) {
+    dim3 grid((unsigned)(8 * ((n_chunks + 7) / 8) * nco * nci));
+    const size_t lds_dma = 3 * ((size_t)128 * 128 + (size_t)128 * 256);      // three stage buffers in window mode
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    conv_wgrad_dma_kernel<2><<<grid, 512, lds_dma, stream>>>(a, (const __bf16*)d->zero_page);
+    SMT_CHECK_LAUNCH("conv_wgrad_dma");
+  }
+  return launch_wgrad_reduce((const float*)workspace, dweight, dbias, d->batch > 0 ? n_chunks : 0, nco, nci, 1, v->c_in,
+                             d->c_out, 128, stride_out, stride_in, stride_tap, tap_map, stream, 1, /*vsplit=*/64);
+}
+
 extern "C" const char* smt_conv1d_wgrad_kernel_name(const smt_conv_desc* d) {
   if (!d) return "";
   ShiftPlan pl;
   if (wgrad_shift_plan(d, &pl)) return "conv_wgrad_shift";
+  smt_conv_desc wv;
+  if (wgrad_window_desc(d, &wv)) return "conv_wgrad_dma";
   const smt_conv_desc g = wgrad_group_desc(d, 0, std::min(WG_GROUP, d->taps));
   const int rows_x = 127 * g.stride + (g.taps - 1) * (wgrad_rs(&g) > 1 ? 1 : g.dilation) + 1;
   const size_t lds_dma = 2 * ((size_t)128 * 128 + (size_t)((rows_x + 3) & ~3) * 256);
@@ -901,6 +981,9 @@ extern "C" int smt_conv1d_wgrad(const smt_conv_desc* d, float* dweight, int64_t 
                                d->c_in, d->c_out, 128, stride_out, stride_in, stride_tap, tap_map, stream, 4);
   }
   SMT_CHECK_ARG(workspace_bytes >= smt_conv1d_wgrad_workspace_bytes(d), "smt_conv1d_wgrad: workspace too small");
+  smt_conv_desc wv;
+  if (wgrad_window_desc(d, &wv))
+    return wgrad_window(d, &wv, dweight, stride_out, stride_in, stride_tap, tap_map, dbias, workspace, workspace_bytes, stream);
   size_t off = 0;
   for (int j0 = 0; j0 < d->taps; j0 += WG_GROUP) {
     smt_conv_desc g = wgrad_group_desc(d, j0, std::min(WG_GROUP, d->taps - j0));

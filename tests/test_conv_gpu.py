@@ -597,6 +597,76 @@ def test_fused_gate_conv_backward_matches_separate_kernels(b, t):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,c_out,b,t", [("down", 64, 3, 2000), ("down", 128, 2, 9002), ("up0", 64, 3, 1500), ("up1", 128, 2, 7001),
+                                            ("down", 64, 1, 2)])
+def test_window_mode_weight_gradient_of_the_resampling_convs(kind, c_out, b, t, monkeypatch):
+    """Weight / bias gradients of the 64-channel k = 4, stride-2 conv ("down": dW[co][ci][j] = sum dy[t][co] x[2t - 1 + j][ci])
+    and of the two 2-tap phases of its transpose ("up0": rows x[m - 1], x[m] against dy[2m]; "up1": x[m], x[m + 1] against
+    dy[2m + 1]) on the LDS-DMA kernel's window mode, against float64 sums and against the generic kernel (descriptor without
+    zero_page); ragged input lengths, one-hot dy picks out the input rows exactly."""
+    import ctypes
+    from smt_amd import convops as C
+    monkeypatch.setenv("SMT_WGRAD_WINDOW", "1")            # opt-in: measured slower than the generic kernel (DESIGN section 3)
+    g = torch.Generator(device="cuda").manual_seed(7 * t + c_out)
+    bf = torch.bfloat16
+    if kind == "down":
+        t_in, t_out, taps, stride, pad, os_, oo = 2 * t, t, 4, 2, 1, 1, 0
+        t_y = t
+    else:
+        t_in, t_out, taps, stride, os_ = t, t, 2, 1, 2
+        pad, oo = (1, 0) if kind == "up0" else (0, 1)
+        t_y = 2 * t
+    x = torch.randn(b, t_in, 64, device="cuda", generator=g).to(bf)
+    dy = torch.randn(b, t_y, c_out, device="cuda", generator=g).to(bf)
+    lens = torch.tensor([t_in, max(1, t_in // 3), 1][:b], device="cuda", dtype=torch.int32)
+
+    def run(fast, dout):
+        dw = torch.full((c_out, 64, taps), 9.0, device="cuda")
+        db = torch.full((c_out,), 9.0, device="cuda")
+        d = C._base_desc(x, dout, lens, 64, c_out, taps, stride, 1, pad, t_out, t_y=t_y, out_stride=os_, out_offset=oo)
+        lib = C.N.lib()
+        if fast:
+            d.zero_page = C._p(C._zero_page(x.device))
+        name = lib.smt_conv1d_wgrad_kernel_name(ctypes.byref(d)).decode()
+        ws = torch.empty(max(16, lib.smt_conv1d_wgrad_workspace_bytes(ctypes.byref(d))), dtype=torch.uint8, device="cuda")
+        arr = (ctypes.c_int * taps)(*range(taps))
+        C.N.check(lib.smt_conv1d_wgrad(ctypes.byref(d), C._p(dw), 64 * taps, taps, 1, arr, C._p(db), C._p(ws), ws.numel(),
+                                       C.N.stream_ptr()), "smt_conv1d_wgrad")
+        torch.cuda.synchronize()
+        return name, dw, db
+
+    n0, dw0, db0 = run(False, dy)
+    n1, dw1, db1 = run(True, dy)
+    assert (n0, n1) == ("conv_wgrad", "conv_wgrad_dma")
+    # float64 reference
+    xm = x.double().clone()
+    for i in range(b):
+        xm[i, int(lens[i]):] = 0
+    dyr = dy.double()[:, oo::os_][:, :t_out]
+    ref = torch.zeros(c_out, 64, taps, dtype=torch.float64, device="cuda")
+    for j in range(taps):
+        rows = stride * torch.arange(t_out, device="cuda") - pad + j
+        ok = (rows >= 0) & (rows < t_in)
+        xs = torch.zeros(b, t_out, 64, dtype=torch.float64, device="cuda")
+        xs[:, ok] = xm[:, rows[ok]]
+        ref[:, :, j] = torch.einsum("bto,bti->oi", dyr, xs)
+    tol = 2e-6 * float(ref.abs().max()) * (b * t_out) ** 0.5 + 1e-4
+    assert float((dw1.double() - ref).abs().max()) <= tol and float((dw0.double() - ref).abs().max()) <= tol
+    dbr = dyr.sum((0, 1))
+    assert float((db1.double() - dbr).abs().max()) <= 2e-6 * float(dbr.abs().max()) * (b * t_out) ** 0.5 + 1e-3
+    if t_out >= 1000:                                       # one-hot dy: the gradient IS the shifted input rows
+        hot = torch.zeros_like(dy)
+        m = 777
+        hot[1, m * os_ + oo, 5] = 1
+        _, dwh, dbh = run(True, hot)
+        for j in range(taps):
+            r = stride * m - pad + j
+            want = x[1, r].float() if r < int(lens[1]) else torch.zeros(64, device="cuda")
+            assert torch.equal(dwh[5, :, j], want)
+        assert float(dwh[:5].abs().max()) == 0 and float(dbh.sum()) == 1.0
+
+
+@pytest.mark.gpu
 def test_full_size_linearity_of_the_dilated_conv_kernels():
     """BASELINE.json's full size of the top level (B = 32, T = 72,704, 128 channels, k = 9, dilation 27): scaling the
     input by a power of two scales a bias-free bf16 convolution and its weight gradient exactly (bit-for-bit), zero

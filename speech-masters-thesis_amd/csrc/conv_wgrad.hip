@@ -609,26 +609,26 @@ struct WreduceJob {
 constexpr int WR_MAXJ = 16;
 struct WreduceBatch { int n_jobs, total_blocks; WreduceJob job[WR_MAXJ]; };
 
-// Weight part: a workgroup owns 32 float4 outputs (128 consecutive ci of one (plane, co) row... up to row ends) x 8
-// chunk slices: thread (o, s) sums chunks s, s+8, ... in index order (four independent 16-byte loads in flight), the
-// eight slice sums are then added in slice order -- the same fixed summation tree as the first version of this kernel
-// (one float per thread, one load in flight: latency-bound, 17 us per call whatever the size), so the results are
-// bit-identical to it and bitwise reproducible.  Bias part: one thread per output channel and slice, columns 0, 32, ..
+// Weight part: a workgroup owns 64 float4 outputs (256 consecutive ci of one (plane, co) row ... up to row ends) x 4 chunk
+// slices: thread (o, s) sums chunks s, s+4, ... in index order (four independent 16-byte loads in flight; eight measured the same), the four slice
+// sums are then added in slice order -- a fixed summation tree: bitwise reproducible.  (Round 3: a wave now reads ONE
+// 1 KiB run of one slab per load instruction; the first layout -- 32 outputs x 8 slices, two 512-byte runs of two slabs per
+// instruction -- read the slabs at 2.5-3 TB/s.)  Bias part: one thread per output channel and slice (32 x 8), columns 0, 32, ..
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(WreduceBatch bt) {
-  __shared__ f32x4 part[8][32];
+  __shared__ f32x4 part[4][64];
   int j = 0;
 #pragma unroll 1
   for (int k = 1; k < bt.n_jobs; ++k)
     if ((int)blockIdx.x >= bt.job[k].block0) j = k;
   const WreduceJob& p = bt.job[j];
   const int lb = blockIdx.x - p.block0;
-  const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const size_t blk_elems = (size_t)p.planes * 64 * p.cib;
   const size_t cstride = (size_t)p.nblk * blk_elems;
   if (lb < p.wblocks) {
+    const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int cin4 = p.Cin >> 2;
     const long long total4 = (long long)p.taps * p.Cout * cin4;
-    const long long e4 = (long long)lb * 32 + o;
+    const long long e4 = (long long)lb * 64 + o;
     const bool live = e4 < total4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     int ci = 0, co = 0, plane = 0;
@@ -637,27 +637,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(WreduceBatch bt)
       const int blk = (co / 64) * p.nblk_ci + (ci / p.cib);
       const float* src = p.slab + (size_t)blk * blk_elems + ((size_t)plane * 64 + (co % 64)) * p.cib + (ci % p.cib);
       int c = sl;
-      for (; c + 24 < p.n_chunks; c += 32) {
+      for (; c + 12 < p.n_chunks; c += 16) {
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + (size_t)c * cstride);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + (size_t)(c + 8) * cstride);
-        const f32x4 v2 = *reinterpret_cast<const f32x4*>(src + (size_t)(c + 16) * cstride);
-        const f32x4 v3 = *reinterpret_cast<const f32x4*>(src + (size_t)(c + 24) * cstride);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + (size_t)(c + 4) * cstride);
+        const f32x4 v2 = *reinterpret_cast<const f32x4*>(src + (size_t)(c + 8) * cstride);
+        const f32x4 v3 = *reinterpret_cast<const f32x4*>(src + (size_t)(c + 12) * cstride);
         s += v0; s += v1; s += v2; s += v3;
       }
-      for (; c < p.n_chunks; c += 8) s += *reinterpret_cast<const f32x4*>(src + (size_t)c * cstride);
+      for (; c < p.n_chunks; c += 4) s += *reinterpret_cast<const f32x4*>(src + (size_t)c * cstride);
     }
     part[sl][o] = s;
     __syncthreads();
     if (sl == 0 && live) {
       f32x4 t = part[0][o];
 #pragma unroll
-      for (int k = 1; k < 8; ++k) t += part[k][o];
+      for (int k = 1; k < 4; ++k) t += part[k][o];
       float* dst = p.vsplit > 0 ? p.dw + co * p.so + (ci % p.vsplit) * p.si + p.jmap[ci / p.vsplit] * p.sj
                                 : p.dw + co * p.so + ci * p.si + p.jmap[plane] * p.sj;
       dst[0] = t[0]; dst[p.si] = t[1]; dst[2 * p.si] = t[2]; dst[3 * p.si] = t[3];
     }
   } else {
     float* part1 = reinterpret_cast<float*>(&part[0][0]);      // [8][32]
+    const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int co = (lb - p.wblocks) * 32 + o;
     const bool live = co < p.Cout && p.db != nullptr;
     float s = 0.f;
@@ -750,7 +751,7 @@ int launch_wgrad_reduce(const float* slab, float* dw, float* db, int n_chunks, i
   const int n_map = vsplit > 0 ? c_in / vsplit : taps;      // window mode: one entry per real tap
   for (int t = 0; t < 16; ++t) r.jmap[t] = (signed char)(t < n_map ? jmap[t] : 0);
   const long long total4 = (long long)taps * c_out * (c_in / 4);
-  r.wblocks = (int)((total4 + 31) / 32);
+  r.wblocks = (int)((total4 + 63) / 64);
   r.block0 = g_reduce_batch.total_blocks;
   g_reduce_batch.total_blocks += r.wblocks + (db ? (c_out + 31) / 32 : 0);
   g_reduce_batch.n_jobs += 1;

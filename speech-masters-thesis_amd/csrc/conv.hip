@@ -1853,15 +1853,16 @@ static int launch_conv_k1act(ConvArgs p, const void* zero_page, hipStream_t stre
 // ------------------------------------------------------------------------------------------------
 // The gate conv of GatedHiFiBlock, forward (reference models/vqvae/resnet.py:238-241): out = W g + b + x, a 64 -> 64 1 x 1
 // conv with the block input as residual -- 128 B + 128 B in, 128 B out per row.  It ran on the generic register-staged
-// kernel at 4 % of its roofs (1.07 ms/step over the 14 blocks; the bytes allow 0.3).  Same machine as conv_k1act: persistent
-// workgroups (two per CU), the 64 x 64 weight block in registers (wave w: output channels 32 (w & 1).., rows 32 (w >> 1)..),
+// kernel (1.07 ms/step over the 14 blocks; now 0.8 ms = 4.7 TB/s at the top level).  Same machine as conv_k1act: persistent
+// workgroups (four waves, 64-row tiles, up to four per CU), the 64 x 64 weight block in registers (wave w: output channels
+// 32 (w & 1).., rows 32 (w >> 1)..),
 // g and x tiles through an untracked LDS-DMA double buffer, transposed MFMA tile, the generic epilogue's arithmetic element
 // by element -- out = bf16(bf16(acc + b) * keep_row + x) -- v_permlane32_swap pairing, 16-byte stores through a V#, one
 // counted wait per tile.
-constexpr int C64_ROWS = 128, C64_NT = 512, C64_TILE = C64_ROWS * 128;
+constexpr int C64_ROWS = 64, C64_NT = 256, C64_TILE = C64_ROWS * 128;   // four waves: 32 output channels x 32 rows each
 
 __global__ __launch_bounds__(C64_NT) void conv1x1_c64_kernel(ConvArgs p, int tiles_per_wg) {
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // 2 x [g tile | x tile], 128 rows x 128 B each
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // 2 x [g tile | x tile], 64 rows x 128 B each
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int ct = wave & 1, rg = wave >> 1;
@@ -1901,8 +1902,8 @@ __global__ __launch_bounds__(C64_NT) void conv1x1_c64_kernel(ConvArgs p, int til
     unsigned char* base = smem + (size_t)buf * 2 * C64_TILE + wave * 1024;
 #pragma unroll
     for (int q = 0; q < (C64_ROWS / 8) / (C64_NT / 64); ++q) {     // 8 rows x 8 chunks per instruction
-      untracked_dma16(rx, (unsigned)(t0 + srow + 64 * q) * pitch_x + schunk, base + q * (C64_NT / 64) * 1024);
-      untracked_dma16(rr, (unsigned)(t0 + srow + 64 * q) * pitch_r + schunk, base + C64_TILE + q * (C64_NT / 64) * 1024);
+      untracked_dma16(rx, (unsigned)(t0 + srow + 8 * (C64_NT / 64) * q) * pitch_x + schunk, base + q * (C64_NT / 64) * 1024);
+      untracked_dma16(rr, (unsigned)(t0 + srow + 8 * (C64_NT / 64) * q) * pitch_r + schunk, base + C64_TILE + q * (C64_NT / 64) * 1024);
     }
   };
 
@@ -1974,7 +1975,7 @@ static bool conv1x1_c64_eligible(const smt_conv_desc* d) {
 static int launch_conv1x1_c64(ConvArgs p, hipStream_t stream) {
   p.tiles_per_batch = (p.Tout + C64_ROWS - 1) / C64_ROWS;
   const int ntiles = p.tiles_per_batch * p.B;
-  int nwg = std::min(512, std::max(8, (ntiles + 1) / 2));     // two workgroups per CU (64 KiB of LDS each)
+  int nwg = std::min(1024, std::max(8, (ntiles + 1) / 2));    // four workgroups per CU (32 KiB of LDS, four waves each)
   nwg = (nwg + 7) / 8 * 8;
   const int tpw = (ntiles + nwg - 1) / nwg;
   (void)hipFuncSetAttribute((const void*)conv1x1_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * C64_TILE);

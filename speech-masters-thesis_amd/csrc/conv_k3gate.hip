@@ -228,7 +228,7 @@ __global__ __launch_bounds__(KG_NT) void conv_k3gate_kernel(K3GateArgs p, const 
                   den += ex;
                   num += ex * gate_tanh(tv[dd]);
                 }
-                o[half] = num / den;
+                o[half] = num * __builtin_amdgcn_rcpf(den);           // bf16 result: one reciprocal (1 ulp), as gate_mix_fwd_kernel<bf16> does
                 __builtin_amdgcn_sched_barrier(0);            // one element at a time: the temporaries of several
               }                                               // elements in flight at once would spill the history
               gq[2 * q + kp] = pack_bf16x2(o[0], o[1]);

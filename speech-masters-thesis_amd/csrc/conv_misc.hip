@@ -45,7 +45,10 @@ __global__ __launch_bounds__(256) void gate_mix_fwd_kernel(const T* __restrict__
         den += ex;
         num += ex * gate_tanh(tv[d][e]);
       }
-      out.v[e] = (T)(num / den);
+      // bf16 results: one reciprocal (1 ulp) instead of an IEEE division (the fused forward, conv_k3gate, does the same: the two
+      // stay bit-identical); the fp32 parity path keeps the division
+      if constexpr (sizeof(T) == 2) out.v[e] = (T)(num * __builtin_amdgcn_rcpf(den));
+      else out.v[e] = (T)(num / den);
     }
     *reinterpret_cast<Vec<T, EPV>*>(g + row * ldg + c) = out;
   }

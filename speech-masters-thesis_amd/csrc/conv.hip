@@ -766,7 +766,7 @@ __global__ __launch_bounds__(WS_NT) void conv_ws_kernel(ConvArgs p, const __bf16
   auto stage_a = [&](int tile, int buf) {
     int b, cls, t0;
     decode(tile, b, cls, t0);
-    const int len_full = p.lens_in ? min(p.lens_in[b], p.Tin) : p.Tin;
+    const int len_full = p.lens_in ? min(scalar_load_i32(p.lens_in + b), p.Tin) : p.Tin;
     const int len_in = max(0, (len_full - cls + rs - 1) / rs);
     const __amdgpu_buffer_rsrc_t rx = ws_rsrc(p.x, ((long long)b * p.x_bs + (long long)cls * p.ldx) * 2, (unsigned)len_in * pitch_x);
     unsigned vo = voff_a0 + (unsigned)(t0 - p.pad) * pitch_x;      // rows before the item wrap to huge offsets: zero
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(WS_NT) void conv_ws_kernel(ConvArgs p, const __bf16
 
     // ---- epilogue straight from the accumulators; same arithmetic as the other kernels: bf16(acc + bias) first.
     // Stores go through range-checked buffer descriptors (rows >= Tc are dropped by the hardware, 32-bit offsets).
-    const int len_out = p.lens_out ? p.lens_out[b] : 0x7fffffff;
+    const int len_out = p.lens_out ? scalar_load_i32(p.lens_out + b) : 0x7fffffff;
     const unsigned pitch_y = (unsigned)p.ldy * rs * 2u, pitch_u = (unsigned)p.ldya * rs * 2u;
     const __amdgpu_buffer_rsrc_t ry = ws_rsrc(has_y ? p.y : p.x, has_y ? ((long long)b * p.y_bs + (long long)cls * p.ldy + n0 + wave * 32) * 2 : 0,
                                               has_y ? (unsigned)Tc * pitch_y : 0u);
@@ -1089,7 +1089,7 @@ __global__ __launch_bounds__(WS_NT) void conv_ws_pipe_kernel(ConvArgs p, const _
   auto stage_a = [&](int tile, int buf) {
     int b, cls, t0;
     decode(tile, b, cls, t0);
-    const int len_full = p.lens_in ? min(p.lens_in[b], p.Tin) : p.Tin;
+    const int len_full = p.lens_in ? min(scalar_load_i32(p.lens_in + b), p.Tin) : p.Tin;
     const int len_in = max(0, (len_full - cls + rs - 1) / rs);
     const __amdgpu_buffer_rsrc_t rx = ws_rsrc(p.x, ((long long)b * p.x_bs + (long long)cls * p.ldx) * 2, (unsigned)len_in * pitch_x);
     unsigned vo = voff_a0 + (unsigned)(t0 - p.pad) * pitch_x;
@@ -1237,7 +1237,7 @@ __global__ __launch_bounds__(WS_NT) void conv_ws_pipe_kernel(ConvArgs p, const _
     p_b = b; p_cls = cls; p_t0 = t0;
     p_ru = ws_rsrc(p.y_act, ((long long)b * p.ya_bs + n0 + wave * 32) * 2, (unsigned)p.Ty * ((unsigned)p.ldya * 2u));
     p_Tc = (p.Tout - cls + rs - 1) / rs;
-    p_len = p.lens_out ? p.lens_out[b] : 0x7fffffff;
+    p_len = p.lens_out ? scalar_load_i32(p.lens_out + b) : 0x7fffffff;
   }
   static_for<0, PH_TILE>(epi);                          // epilogue of the last tile
 }
@@ -1348,7 +1348,7 @@ __global__ __launch_bounds__(WS2_NT) void conv_ws2_kernel(ConvArgs p, const __bf
   auto stage_a = [&](int tile, int buf) {
     int b, cls, t0;
     decode(tile, b, cls, t0);
-    const int len_full = p.lens_in ? min(p.lens_in[b], p.Tin) : p.Tin;
+    const int len_full = p.lens_in ? min(scalar_load_i32(p.lens_in + b), p.Tin) : p.Tin;
     const int len_in = max(0, (len_full - cls + rs - 1) / rs);
     const __amdgpu_buffer_rsrc_t rx = ws_rsrc(p.x, ((long long)b * p.x_bs + (long long)cls * p.ldx) * 2, (unsigned)len_in * pitch_x);
     const unsigned s0 = (unsigned)(t0 - p.pad) * pitch_x;       // rows before the item wrap to huge offsets: out of range, zero
@@ -1369,7 +1369,7 @@ __global__ __launch_bounds__(WS2_NT) void conv_ws2_kernel(ConvArgs p, const __bf
   // ---- epilogue of one tile half straight from the accumulators (the arithmetic of conv_ws_kernel, written for few VALU
   //      instructions: the epilogue, not the matrix pipe, bounds this kernel at 3 taps)
   auto epilogue = [&](int b, int cls, int t0, int Tc) {
-    const int len_out = p.lens_out ? p.lens_out[b] : 0x7fffffff;
+    const int len_out = p.lens_out ? scalar_load_i32(p.lens_out + b) : 0x7fffffff;
     const __amdgpu_buffer_rsrc_t ry =
         MODE == 2 ? ws_rsrc(p.y, ((long long)b * p.y_bs + (long long)cls * p.ldy + n0 + cw * 32) * 2, (unsigned)Tc * pitch_o)
                   : ws_rsrc(p.y_act, ((long long)b * p.ya_bs + (long long)cls * p.ldya + n0 + cw * 32) * 2, (unsigned)Tc * pitch_o);

@@ -112,7 +112,8 @@ __device__ __forceinline__ void untracked_load8(const void* sbase, unsigned voff
 // and waits vmcnt(0) for it -- draining the LDS-DMA in flight); the address must be wave-uniform.
 __device__ __forceinline__ int scalar_load_i32(const int* ptr) {
   int v;
-  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ptr) : "memory");
+  asm volatile("s_nop 4\n\ts_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ptr) : "memory");   // s_nop: the address may
+                                                        // come from v_readfirstlane (VALU-written SGPR read by a memory instruction)
   return v;
 }
 

@@ -458,7 +458,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_shift_kernel(ShiftArgs p, cons
     const T* xg = reinterpret_cast<const T*>(p.x) + (long long)b * p.x_bs + (long long)cls * p.ldx + ci0;
     const T* dyg = reinterpret_cast<const T*>(p.dy) + (long long)b * p.dy_bs + (long long)cls * p.ldy + co0;
     const long long ldx = (long long)p.ldx * rs, ldy = (long long)p.ldy * rs;
-    const int len_full = p.lens_in ? min(p.lens_in[b], p.Tin) : p.Tin;
+    const int len_full = p.lens_in ? min(scalar_load_i32(p.lens_in + b), p.Tin) : p.Tin;
     const int len_in = max(0, (len_full - cls + rs - 1) / rs);
     unsigned char* base = smem + (size_t)buf * SH_STAGE;
     // dy: 128 rows x 8 chunks; one wave-instruction = 8 rows
